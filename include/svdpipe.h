@@ -1,0 +1,163 @@
+/* svdpipe.h – C ABI of libsvdpipe_hip.so, the MI355X (gfx950) kernel library under the
+ * per-step SVD UNet hot path.
+ *
+ * The reference (inai17ibar/video-diffusion-pipeline-parallel) defines NO FFI: its hot path is the
+ * Python call `latent = self.model(latent, step)` (/root/reference/src/pipeline/pipeline.py:95)
+ * -> `StableVideoUNet.forward` (/root/reference/src/models/svd_unet.py:351-439)
+ * -> `self.unet(sample=..., timestep=..., encoder_hidden_states=..., added_time_ids=...)`
+ *    (svd_unet.py:389,400,416), where `unet` is diffusers' UNetSpatioTemporalConditionModel running
+ *    on cuDNN/cuBLAS/xformers.  The entry points below are what a binding for that path binds
+ *    instead of those vendor libraries; each comment names the diffusers/torch op it replaces and
+ *    the reference line that reaches it.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes; `stream` is a hipStream_t passed as void* (NULL = default stream)
+ *   - device pointers are owned by the caller (PyTorch allocator); the library never allocates,
+ *     frees or synchronises; every call only enqueues kernels on `stream`
+ *   - return 0 on success, negative SP_E* on a rejected argument (nothing is launched);
+ *     sp_last_error() returns a thread-local message
+ *   - activations are fp16, channels-last: a "token matrix" [rows][C] where rows enumerate
+ *     (frame, y, x) in that order (NHWC per frame); weights are fp16 [N][K] (K contiguous);
+ *     biases / norm affine parameters are fp32
+ *   - gfx950 code objects only
+ */
+#ifndef SVDPIPE_H
+#define SVDPIPE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_OK 0
+#define SP_EINVAL (-1)   /* bad argument / unsupported shape */
+#define SP_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
+
+const char *sp_last_error(void);
+int sp_version(void);
+/* bytes of zero-filled device memory every gather kernel needs behind `zero_page` */
+#define SP_ZERO_PAGE_BYTES 4096
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit-GEMM family:  D[M][Nout] = epilogue( sum_{tap,k} A_tap[m][k] * W[n][tap*Cin + k] )
+ * Replaces torch.nn.functional.conv2d (ResnetBlock2D conv1/conv2, Downsample2D, Upsample2D conv,
+ * conv_in/conv_out), conv3d with kernel (3,1,1) (TemporalResnetBlock), 1x1 shortcut convs and every
+ * nn.Linear of the transformer blocks – i.e. cuDNN/cuBLAS under svd_unet.py:416.
+ * MFMA fp16 -> fp32 accumulate; A tiles are gathered straight from the NHWC tensor into LDS
+ * (no im2col buffer).
+ * ------------------------------------------------------------------------------------------- */
+enum { SP_A_LINEAR = 0, SP_A_CONV3X3 = 1, SP_A_TEMPORAL3 = 2 };
+
+typedef struct sp_gemm_desc {
+  /* A operand */
+  const void *a;        /* fp16 [rows_in][lda] */
+  int64_t lda;          /* elements between consecutive A rows (>= cin) */
+  int mode;             /* SP_A_* */
+  int cin;              /* channels per tap (multiple of 64); K = taps*cin */
+  /* geometry for SP_A_CONV3X3: input images [n_img][hin][win], output [n_img][hout][wout];
+     pad 1; stride 1 or 2; upsample2x!=0 reads the input through a nearest-neighbour x2 upsample */
+  int n_img, hin, win, hout, wout, stride, upsample2x;
+  /* geometry for SP_A_TEMPORAL3: rows = [batch][frames][hw]; taps are frames f-1, f, f+1 */
+  int frames; int64_t hw;
+  /* B operand */
+  const void *w;        /* fp16 [n][taps*cin]; for geglu the rows are pre-interleaved in blocks of 16 */
+  int m, n;             /* GEMM M (output rows) and N (weight rows; multiple of 64) */
+  /* epilogue: v = oscale*(acc + bias[n] + bias2[(m/bias2_rows)][n]) + r1scale*res1 + r2scale*res2
+     geglu!=0: out[m][j] = h*gelu(gate) over the interleaved column pairs, Nout = n/2
+     (bias applies before gelu; oscale/res are applied to the product) */
+  const float *bias;    /* [n] or NULL */
+  const float *bias2;   /* [nb][n] or NULL */
+  int64_t bias2_rows;   /* rows of D sharing one bias2 row (e.g. H*W of a frame) */
+  const void *res1; int64_t ldr1; float r1scale;   /* fp16 [m][ldr1] or NULL */
+  const void *res2; int64_t ldr2; float r2scale;
+  float oscale;
+  int geglu;
+  int n_store;          /* number of leading output columns actually stored (<= Nout); 0 = all */
+  void *d; int64_t ldd; /* fp16 [m][ldd] */
+  const void *zero_page;
+} sp_gemm_desc;
+
+int sp_gemm_f16(const sp_gemm_desc *desc, void *stream);
+
+/* y[n] = act_out( W[n][:] . act_in(x) + b[n] ), M = 1.  Replaces the nn.Linear GEMVs of the
+ * timestep / added-time / frame-position embeddings and every `time_emb_proj` (diffusers
+ * TimestepEmbedding, ResnetBlock2D.time_emb_proj).  x, W fp16; b, y fp32 (y_f16 optional copy).
+ * silu_in / silu_out apply SiLU to the input vector / output. `rows` independent input vectors. */
+int sp_gemv_f16(const void *x, int64_t ldx, const void *w, const float *b, float *y, void *y_f16,
+                int64_t ldy, int rows, int n, int k, int silu_in, int silu_out, void *stream);
+
+/* Sinusoidal embedding [cos | sin] (diffusers Timesteps(dim, flip_sin_to_cos=True, shift=0)) of
+ * `count` fp32 values read from device memory; writes fp16 [count][dim]. */
+int sp_sinusoid_f16(const float *values, void *out, int count, int dim, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU), channels-last.  Replaces torch.nn.GroupNorm + F.silu in
+ * ResnetBlock2D / TemporalResnetBlock / TransformerSpatioTemporalModel.norm / conv_norm_out.
+ * x,y: fp16 [instances][rows][C]; statistics are taken per (instance, group) over rows x C/groups.
+ * Spatial norm: instance = frame; temporal norm: instance = batch (rows = frames*H*W).
+ * ws: >= sp_groupnorm_ws_bytes() bytes of scratch.
+ * ------------------------------------------------------------------------------------------- */
+size_t sp_groupnorm_ws_bytes(int instances, int64_t rows, int c, int groups);
+int sp_groupnorm_f16(const void *x, const float *gamma, const float *beta, void *y, int instances,
+                     int64_t rows, int c, int groups, float eps, int fuse_silu, void *ws,
+                     size_t ws_bytes, void *stream);
+
+/* LayerNorm over the last dim (torch.nn.LayerNorm in BasicTransformerBlock /
+ * TemporalBasicTransformerBlock).  Optional pre-add of a per-frame vector
+ * (`hidden_states_mix = hidden_states + emb`): xin = x + addvec[row / addvec_rows]; if `sum_out`
+ * is non-NULL the pre-norm sum is stored there as well.  fp16 in/out, fp32 affine. */
+int sp_layernorm_f16(const void *x, const void *addvec, int64_t addvec_rows, void *sum_out,
+                     const float *gamma, const float *beta, void *y, int64_t rows, int c, float eps,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention.  Replaces F.scaled_dot_product_attention / xformers (svd_unet.py:142) for
+ *  - spatial self-attention: sequences of `seq` tokens, `batch` of them (one per frame),
+ *    q,k,v,o fp16 [batch*seq][heads*64] with row stride ld* (so q,k,v may alias one fused QKV buffer)
+ *  - temporal self-attention: sequences run ACROSS frames for every pixel; token (f, p) lives at
+ *    row f*hw + p, so no permute is materialised.
+ * head_dim is fixed at 64 (all SVD levels).  softmax scale = 1/8.  zero_page: SP_ZERO_PAGE_BYTES of
+ * zero-filled device memory (padding rows are read from it).
+ * ------------------------------------------------------------------------------------------- */
+int sp_attn_spatial_f16(const void *q, const void *k, const void *v, void *o, int64_t ldq,
+                        int64_t ldk, int64_t ldv, int64_t ldo, int batch, int seq, int heads,
+                        float scale, const void *zero_page, void *stream);
+int sp_attn_temporal_f16(const void *q, const void *k, const void *v, void *o, int64_t ldq,
+                         int64_t ldk, int64_t ldv, int64_t ldo, int batch, int frames, int64_t hw,
+                         int heads, float scale, const void *zero_page, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout / elementwise glue around the UNet (svd_unet.py:382-439).
+ * ------------------------------------------------------------------------------------------- */
+/* latent (B,4,F,H,W) * in_scale  ++  image_latents (B,4,F,H,W)  ->  NHWC rows [B*F*H*W][cpad]
+ * (channels 0-3 scaled latent, 4-7 image latents, rest zero): svd_unet.py:382,414-415 */
+int sp_pack_input_f16(const void *latent, const void *image_latents, void *out, float in_scale,
+                      int b, int frames, int h, int w, int cpad, void *stream);
+/* v-prediction Euler update with optional CFG, fp32 math (svd_unet.py:410-411,425-439):
+ * eps = eps_u + gs[f]*(eps_c - eps_u) if eps_uncond!=NULL else eps_c;
+ * x' = x + ((x - (eps*c_out + x*c_skip))/sigma)*dt.  eps_* are NHWC [B*F*H*W][ld_eps]; latent and
+ * out are (B,4,F,H,W). */
+int sp_euler_step_f16(const void *latent, const void *eps_cond, const void *eps_uncond,
+                      int64_t ld_eps, const float *guidance /*[F] or NULL*/, void *out, float sigma,
+                      float sigma_next, int b, int frames, int h, int w, void *stream);
+/* channel concat of two NHWC tensors (torch.cat([hidden, skip], dim=1) in the up blocks) */
+int sp_concat_channels_f16(const void *a, int ca, const void *b, int cb, void *out, int64_t rows,
+                           void *stream);
+/* y = x + vec[c] broadcast over rows (used for the degenerate single-token cross-attention) */
+int sp_add_rowvec_f16(const void *x, const float *vec, void *y, int64_t rows, int c, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DummyUNet (simulator-path model, /root/reference/src/models/dummy_unet.py:37-59), fp32 NCDHW:
+ * out = x + gain*Conv3d(SiLU(Conv3d(x))) + LayerNorm_C(x).  hidden: scratch [B][hidden][F][H][W].
+ * ------------------------------------------------------------------------------------------- */
+int sp_dummy_unet_f32(const float *x, float *out, float *hidden, const float *w1, const float *b1,
+                      const float *w2, const float *b2, const float *ln_w, const float *ln_b,
+                      float ln_eps, int use_ln, float gain, int b, int c, int hidden_c, int frames,
+                      int h, int w, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVDPIPE_H */

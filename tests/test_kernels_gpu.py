@@ -1,0 +1,298 @@
+"""GPU parity tests of every C-ABI kernel against a plain fp32 torch CPU computation of the same op
+on the same fp16-rounded inputs.  Tolerances (stated per test): fp16 storage, fp32 accumulation ->
+relative L2 error <= 2e-3, max abs error <= 1e-2 * max|ref| unless noted."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from vdpp_amd.hip import ops
+    return ops
+
+
+def _w():
+    from vdpp_amd.models import weights
+    return weights
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def check(out, ref, l2=2e-3, mx=1e-2):
+    out = out.float().cpu()
+    assert torch.isfinite(out).all()
+    e = rel_l2(out, ref)
+    m = float((out - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+    assert e <= l2 and m <= mx, f"rel_l2={e:.3e} max_rel={m:.3e}"
+
+
+def h(t):  # fp16-rounded fp32 copy (what the kernel actually sees)
+    return t.half().float()
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (1000, 320, 320), (2016, 1280, 1280), (77, 64, 128),
+                                   (4096, 960, 640), (300, 2560, 320)])
+def test_gemm_linear(m, n, k):
+    ops = _ops()
+    g = torch.Generator().manual_seed(m + n + k)
+    a = h(torch.randn(m, k, generator=g)); w = h(torch.randn(n, k, generator=g) / math.sqrt(k))
+    bias = torch.randn(n, generator=g)
+    res = h(torch.randn(m, n, generator=g))
+    out = torch.empty(m, n, dtype=torch.float16, device=DEV)
+    ops.gemm(a.half().to(DEV), w.half().to(DEV), out, m=m, n=n, cin=k, bias=bias.to(DEV),
+             res1=res.half().to(DEV), r1scale=0.5, oscale=2.0)
+    ref = 2.0 * (a @ w.t() + bias) + 0.5 * res
+    check(out, ref)
+
+
+def test_gemm_two_residuals_bias2_and_nstore():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    m, n, k = 3 * 70, 128, 192
+    a = h(torch.randn(m, k, generator=g)); w = h(torch.randn(n, k, generator=g) / math.sqrt(k))
+    b2 = torch.randn(3, n, generator=g)
+    r1 = h(torch.randn(m, n, generator=g)); r2 = h(torch.randn(m, n, generator=g))
+    out = torch.zeros(m, 100, dtype=torch.float16, device=DEV)
+    # ldd = 104 (multiple of 8), only the first 100 columns are stored
+    outp = torch.zeros(m, 104, dtype=torch.float16, device=DEV)
+    ops.gemm(a.half().to(DEV), w.half().to(DEV), outp, m=m, n=n, cin=k, bias2=b2.to(DEV), bias2_rows=70,
+             res1=r1.half().to(DEV), r1scale=0.25, res2=r2.half().to(DEV), r2scale=-1.5, oscale=0.7,
+             n_store=100, ldd=104, ldr1=n, ldr2=n)
+    ref = 0.7 * (a @ w.t() + b2.repeat_interleave(70, 0)) + 0.25 * r1 - 1.5 * r2
+    check(outp[:, :100], ref[:, :100])
+    assert float(outp[:, 100:].abs().max()) == 0.0
+    del out
+
+
+def test_gemm_geglu():
+    ops, W = _ops(), _w()
+    g = torch.Generator().manual_seed(9)
+    m, k, inner = 500, 128, 512
+    a = h(torch.randn(m, k, generator=g)); w = h(torch.randn(2 * inner, k, generator=g) / math.sqrt(k))
+    b = torch.randn(2 * inner, generator=g)
+    wi, bi = W.interleave_geglu(w, b)
+    out = torch.empty(m, inner, dtype=torch.float16, device=DEV)
+    ops.gemm(a.half().to(DEV), wi.to(DEV), out, m=m, n=2 * inner, cin=k, bias=bi.to(DEV), geglu=True)
+    y = a @ w.t() + b
+    ref = y[:, :inner] * F.gelu(y[:, inner:])
+    check(out, ref)
+
+
+@pytest.mark.parametrize("cin,cout,hh,ww,stride,ups", [(64, 64, 9, 13, 1, 0), (128, 320, 16, 24, 1, 0),
+                                                       (64, 128, 16, 24, 2, 0), (64, 64, 7, 9, 2, 0),
+                                                       (128, 64, 6, 10, 1, 1), (320, 320, 18, 32, 1, 0)])
+def test_gemm_conv3x3(cin, cout, hh, ww, stride, ups):
+    ops, W = _ops(), _w()
+    g = torch.Generator().manual_seed(cin + cout + hh)
+    nimg = 3
+    x = h(torch.randn(nimg, cin, hh, ww, generator=g))
+    w = h(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    b = torch.randn(cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    ref = F.conv2d(xin, w, b, stride=stride, padding=1)
+    ho, wo = ref.shape[2:]
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    out = torch.empty(nimg * ho * wo, cout, dtype=torch.float16, device=DEV)
+    ops.gemm(x_nhwc, W.pack_conv3x3(w).to(DEV), out, m=nimg * ho * wo, n=W.round_up(cout, 64), cin=cin,
+             mode=ops.A_CONV3X3, conv=(nimg, hh, ww, ho, wo, stride, ups), bias=F.pad(b, (0, W.round_up(cout, 64) - cout)).to(DEV),
+             n_store=cout if cout % 64 else 0, ldd=cout)
+    check(out.view(nimg, ho, wo, cout).permute(0, 3, 1, 2), ref)
+
+
+def test_gemm_conv_in_out_padding():
+    """conv_in (Cin=8 padded to 64) and conv_out (Cout=4 padded to 64, 4 columns stored)."""
+    ops, W = _ops(), _w()
+    g = torch.Generator().manual_seed(3)
+    x = h(torch.randn(2, 8, 10, 12, generator=g)); w = h(torch.randn(64, 8, 3, 3, generator=g) / 8)
+    ref = F.conv2d(x, w, None, padding=1)
+    xp = torch.zeros(2, 10, 12, 64); xp[..., :8] = x.permute(0, 2, 3, 1)
+    out = torch.empty(240, 64, dtype=torch.float16, device=DEV)
+    ops.gemm(xp.half().to(DEV), W.pack_conv3x3(w).to(DEV), out, m=240, n=64, cin=64, mode=ops.A_CONV3X3,
+             conv=(2, 10, 12, 10, 12, 1, 0))
+    check(out.view(2, 10, 12, 64).permute(0, 3, 1, 2), ref)
+    w2 = h(torch.randn(4, 64, 3, 3, generator=g) / 24); b2 = torch.randn(4, generator=g)
+    x2 = h(torch.randn(2, 64, 10, 12, generator=g))
+    ref2 = F.conv2d(x2, w2, b2, padding=1)
+    out2 = torch.empty(240, 4, dtype=torch.float16, device=DEV)
+    ops.gemm(x2.permute(0, 2, 3, 1).contiguous().half().to(DEV), W.pack_conv3x3(w2).to(DEV), out2, m=240, n=64,
+             cin=64, mode=ops.A_CONV3X3, conv=(2, 10, 12, 10, 12, 1, 0), bias=F.pad(b2, (0, 60)).to(DEV),
+             n_store=4, ldd=4)
+    check(out2.view(2, 10, 12, 4).permute(0, 3, 1, 2), ref2)
+
+
+@pytest.mark.parametrize("frames,hw,c", [(14, 35, 64), (5, 128, 128), (25, 12, 64)])
+def test_gemm_temporal_conv(frames, hw, c):
+    ops, W = _ops(), _w()
+    g = torch.Generator().manual_seed(frames)
+    bsz = 2
+    x = h(torch.randn(bsz, c, frames, hw, 1, generator=g))
+    w = h(torch.randn(c, c, 3, 1, 1, generator=g) / math.sqrt(3 * c)); b = torch.randn(c, generator=g)
+    ref = F.conv3d(x, w, b, padding=(1, 0, 0))                        # (B,C,F,hw,1)
+    rows = x[..., 0].permute(0, 2, 3, 1).reshape(bsz * frames * hw, c)   # [(b,f,p)][c]
+    out = torch.empty_like(rows, dtype=torch.float16, device=DEV)
+    ops.gemm(rows.half().to(DEV), W.pack_tconv3(w).to(DEV), out, m=rows.shape[0], n=c, cin=c,
+             mode=ops.A_TEMPORAL3, temporal=(frames, hw), bias=b.to(DEV))
+    check(out.view(bsz, frames, hw, c).permute(0, 3, 1, 2), ref[..., 0])
+
+
+@pytest.mark.parametrize("inst,rows,c,silu", [(3, 200, 64, 1), (14, 9 * 16, 320, 1), (1, 14 * 144, 640, 0),
+                                              (2, 1000, 960, 1), (1, 77, 2560, 1), (5, 331, 1280, 0)])
+def test_groupnorm(inst, rows, c, silu):
+    ops = _ops()
+    g = torch.Generator().manual_seed(c + rows)
+    x = h(torch.randn(inst, rows, c, generator=g) * 2 + 0.7)
+    gamma = torch.randn(c, generator=g); beta = torch.randn(c, generator=g)
+    ref = F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, eps=1e-6)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1)
+    ws = torch.empty(ops.groupnorm_ws_bytes(inst, rows, c, 32), dtype=torch.uint8, device=DEV)
+    y = torch.empty(inst, rows, c, dtype=torch.float16, device=DEV)
+    ops.groupnorm(x.half().to(DEV), gamma.to(DEV), beta.to(DEV), y, instances=inst, rows=rows, c=c, groups=32,
+                  eps=1e-6, silu=silu, ws=ws)
+    check(y, ref)
+
+
+@pytest.mark.parametrize("rows,c", [(100, 64), (1000, 320), (513, 640), (130, 1280)])
+def test_layernorm(rows, c):
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows)
+    x = h(torch.randn(rows, c, generator=g) * 3 + 1)
+    gamma = torch.randn(c, generator=g); beta = torch.randn(c, generator=g)
+    y = torch.empty(rows, c, dtype=torch.float16, device=DEV)
+    ops.layernorm(x.half().to(DEV), gamma.to(DEV), beta.to(DEV), y, rows=rows, c=c)
+    check(y, F.layer_norm(x, (c,), gamma, beta))
+    # with the per-frame pre-add (frame positional embedding) and the sum written out
+    per = 50
+    nv = (rows + per - 1) // per
+    add = h(torch.randn(nv, c, generator=g))
+    s = torch.empty(rows, c, dtype=torch.float16, device=DEV)
+    ops.layernorm(x.half().to(DEV), gamma.to(DEV), beta.to(DEV), y, rows=rows, c=c, addvec=add.half().to(DEV),
+                  addvec_rows=per, sum_out=s)
+    xs = (x + add.repeat_interleave(per, 0)[:rows]).half().float()
+    check(s, xs, l2=1e-6, mx=1e-6)
+    check(y, F.layer_norm(xs, (c,), gamma, beta))
+
+
+@pytest.mark.parametrize("batch,seq,heads", [(2, 128, 1), (3, 200, 2), (1, 6, 1), (2, 576, 5), (1, 1000, 3), (1, 2304, 2)])
+def test_attention_spatial(batch, seq, heads):
+    ops = _ops()
+    g = torch.Generator().manual_seed(seq)
+    c = heads * 64
+    qkv = h(torch.randn(batch * seq, 3 * c, generator=g))
+    d = qkv.half().to(DEV)
+    o = torch.empty(batch * seq, c, dtype=torch.float16, device=DEV)
+    ops.attn_spatial(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=batch,
+                     seq=seq, heads=heads)
+    q, k, v = [t.reshape(batch, seq, heads, 64).transpose(1, 2) for t in qkv.split(c, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(batch * seq, c)
+    check(o, ref, l2=3e-3, mx=2e-2)
+
+
+def test_attention_spatial_online_softmax_rescale():
+    """Force a late maximum: one key far down the sequence dominates (exercises the rescale branch)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    seq, c = 700, 64
+    q = h(torch.randn(seq, c, generator=g)); k = h(torch.randn(seq, c, generator=g)); v = h(torch.randn(seq, c, generator=g))
+    k[650] = q[5] * 3.0
+    k[130] = q[77] * 2.0
+    o = torch.empty(seq, c, dtype=torch.float16, device=DEV)
+    ops.attn_spatial(q.half().to(DEV), k.half().to(DEV), v.half().to(DEV), o, ldq=c, ldk=c, ldv=c, ldo=c, batch=1, seq=seq, heads=1)
+    ref = F.scaled_dot_product_attention(q[None, None], k[None, None], v[None, None])[0, 0]
+    check(o, ref, l2=3e-3, mx=2e-2)
+
+
+@pytest.mark.parametrize("batch,frames,hw,heads", [(1, 14, 37, 1), (2, 14, 64, 5), (1, 25, 50, 2), (1, 3, 24, 1), (1, 16, 9, 2)])
+def test_attention_temporal(batch, frames, hw, heads):
+    ops = _ops()
+    g = torch.Generator().manual_seed(frames * hw)
+    c = heads * 64
+    rows = batch * frames * hw
+    qkv = h(torch.randn(rows, 3 * c, generator=g))
+    d = qkv.half().to(DEV)
+    o = torch.empty(rows, c, dtype=torch.float16, device=DEV)
+    ops.attn_temporal(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=batch,
+                      frames=frames, hw=hw, heads=heads)
+    q, k, v = [t.reshape(batch, frames, hw, heads, 64).permute(0, 2, 3, 1, 4) for t in qkv.split(c, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v)              # (b, hw, heads, F, 64)
+    ref = ref.permute(0, 3, 1, 2, 4).reshape(rows, c)
+    check(o, ref, l2=3e-3, mx=2e-2)
+
+
+def test_pack_input_and_euler():
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    b, f, hh, ww = 2, 5, 6, 7
+    lat = h(torch.randn(b, 4, f, hh, ww, generator=g) * 30); img = h(torch.randn(b, 4, f, hh, ww, generator=g))
+    out = torch.empty(b * f * hh * ww, 64, dtype=torch.float16, device=DEV)
+    sigma, sigma_next = 31.5, 20.25
+    scale = 1.0 / math.sqrt(sigma * sigma + 1)
+    ops.pack_input(lat.half().to(DEV), img.half().to(DEV), out, in_scale=scale, b=b, frames=f, h=hh, w=ww, cpad=64)
+    ref = torch.cat([(lat * scale).half().float(), img], dim=1).permute(0, 2, 3, 4, 1).reshape(-1, 8)
+    check(out[:, :8], ref, l2=1e-3, mx=2e-3)
+    assert float(out[:, 8:].abs().max()) == 0.0
+    eps_c = h(torch.randn(b * f * hh * ww, 4, generator=g)); eps_u = h(torch.randn(b * f * hh * ww, 4, generator=g))
+    new = torch.empty_like(lat, dtype=torch.float16, device=DEV)
+
+    def euler(e_rows):
+        e = e_rows.reshape(b, f, hh, ww, 4).permute(0, 4, 1, 2, 3)
+        x0 = e * (-sigma / math.sqrt(sigma ** 2 + 1)) + lat / (sigma ** 2 + 1)
+        return lat + (lat - x0) / sigma * (sigma_next - sigma)
+
+    ops.euler_step(lat.half().to(DEV), eps_c.half().to(DEV), None, None, new, ld_eps=4, sigma=sigma, sigma_next=sigma_next,
+                   b=b, frames=f, h=hh, w=ww)
+    check(new, euler(eps_c), l2=1e-3, mx=2e-3)
+    gs = torch.linspace(1.0, 3.0, f)
+    ops.euler_step(lat.half().to(DEV), eps_c.half().to(DEV), eps_u.half().to(DEV), gs.to(DEV), new, ld_eps=4, sigma=sigma,
+                   sigma_next=sigma_next, b=b, frames=f, h=hh, w=ww)
+    gsr = gs.half().float().repeat_interleave(hh * ww).repeat(b)[:, None]
+    check(new, euler(eps_u + gsr * (eps_c - eps_u)), l2=2e-3, mx=4e-3)
+
+
+def test_concat_addvec_gemv_sinusoid():
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    a = h(torch.randn(100, 64, generator=g)); b = h(torch.randn(100, 128, generator=g))
+    out = torch.empty(100, 192, dtype=torch.float16, device=DEV)
+    ops.concat_channels(a.half().to(DEV), 64, b.half().to(DEV), 128, out, 100)
+    assert torch.equal(out.cpu().float(), torch.cat([a, b], 1))
+    vec = torch.randn(64, generator=g)
+    y = torch.empty(100, 64, dtype=torch.float16, device=DEV)
+    ops.add_rowvec(a.half().to(DEV), vec.to(DEV), y, 100, 64)
+    check(y, a + vec, l2=1e-3, mx=2e-3)
+    x = h(torch.randn(2, 320, generator=g)); w = h(torch.randn(1000, 320, generator=g) / 18); bb = torch.randn(1000, generator=g)
+    y32 = torch.empty(2, 1000, dtype=torch.float32, device=DEV)
+    ops.gemv(x.half().to(DEV), w.half().to(DEV), bb.to(DEV), n=1000, k=320, rows=2, y32=y32, silu_in=True)
+    check(y32, F.silu(x).half().float() @ w.t() + bb, l2=1e-3, mx=2e-3)
+    vals = torch.tensor([1.63777, 5.0, 127.0, 0.02, 0.0, 13.0])
+    so = torch.empty(6, 320, dtype=torch.float16, device=DEV)
+    ops.sinusoid(vals.to(DEV), so, 6, 320)
+    half = 160
+    fr = torch.exp(-math.log(10000.0) * torch.arange(half) / half)
+    ref = torch.cat([torch.cos(vals[:, None] * fr), torch.sin(vals[:, None] * fr)], -1)
+    check(so, ref, l2=2e-3, mx=2e-3)
+
+
+def test_dummy_unet_hip_matches_reference_golden(golden_dir):
+    """HIP DummyUNet vs the vectors minted from the reference (fp32, tolerance 1e-4 relative)."""
+    from vdpp_amd.models import DummyUNet
+    for name, (c, hid) in (("dummy_c8h16.npz", (8, 16)), ("dummy_c4h64.npz", (4, 64))):
+        z = np.load(f"{golden_dir}/{name}")
+        model = DummyUNet(c, hid)
+        model.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")})
+        model = model.to(DEV)
+        lat = torch.from_numpy(z["input"]).to(DEV)
+        with torch.no_grad():
+            for s in z["timesteps"].tolist():
+                lat = model(lat, s)
+        check(lat, torch.from_numpy(z["final"]), l2=1e-5, mx=1e-4)

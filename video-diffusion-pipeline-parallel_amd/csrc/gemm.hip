@@ -1,0 +1,366 @@
+// Implicit-GEMM core for gfx950: D[M][N] = epilogue(sum_tap A_tap[M][Cin] * W[N][tap*Cin + :]^T).
+//
+// One kernel serves every dense contraction of the SVD UNet step:
+//   * SP_A_LINEAR    – nn.Linear / 1x1 convolution (row m of A is row m of the token matrix)
+//   * SP_A_CONV3X3   – 3x3 convolution, pad 1, stride 1|2, optional fused nearest x2 upsample;
+//                      the 9 taps are gathered straight from the NHWC tensor (no im2col buffer)
+//   * SP_A_TEMPORAL3 – (3,1,1) convolution over frames; taps are rows m-hw, m, m+hw
+//
+// Structure (per 256-thread workgroup = 4 waves as 2(M) x 2(N)):
+//   tile 128 x BN x 64, BN in {64,128,160}; A and W tiles are brought in by global_load_lds_dwordx4
+//   (LDS-DMA, 1 KiB per wave instruction = 8 rows x 128 B) into a 2-deep LDS ring; the 16-byte
+//   chunk index is XOR-swizzled on the *source* address ((row>>1)&7) and un-swizzled on the
+//   ds_read_b128, which makes the 16x16x32 operand reads bank-conflict free; MFMA
+//   v_mfma_f32_16x16x32_f16 with the weight tile as the row operand so that each lane ends up with 4
+//   consecutive output channels (8-byte LDS staging writes, 16-byte coalesced global stores).
+//   Out-of-image taps / rows past M read a zero page, so no branch sits in the main loop.
+//   The workgroup -> tile map is XCD-aware: the 8 XCDs each walk a contiguous run of tiles with N
+//   fastest, so an A tile is fetched from HBM once per XCD L2 and re-used by all N tiles.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+constexpr int THREADS = 256;
+
+struct GemmArgs {
+  const f16 *a;
+  const f16 *w;
+  const float *bias;
+  const float *bias2;
+  const f16 *res1;
+  const f16 *res2;
+  f16 *d;
+  const char *zero;
+  int64_t lda, ldr1, ldr2, ldd, hw, bias2_rows;
+  int mode, cin, taps;
+  int n_img, hin, win, hout, wout, stride, ups;
+  int frames;
+  int m, n, k;
+  float oscale, r1scale, r2scale;
+  int geglu, n_store;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // bijective "each XCD gets a contiguous run" remap (blocks b and b+8 share an XCD)
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+template <int BN>
+__global__ __launch_bounds__(THREADS, 2) void gemm_f16_kernel(const GemmArgs p) {
+  constexpr int TN = BN / 32;          // 16-row weight sub-tiles per wave (wave covers BN/2 cols)
+  constexpr int TM = 4;                // 16-col activation sub-tiles per wave (wave covers 64 rows)
+  constexpr int A_BYTES = BM * BK * 2;
+  constexpr int B_BYTES = BN * BK * 2;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int B_LOADS = BN / 32;     // glds per thread for the W tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nwg);
+  const int tile_m = t / p.tiles_n;
+  const int tile_n = t - tile_m * p.tiles_n;
+
+  // ---------------------------------------------------------------- per-lane gather state
+  const int lrow = lane >> 3;                 // row within the 8-row glds piece
+  const int lchunk = lane & 7;                // 16-byte chunk this lane lands in (LDS side)
+  const int cpt = p.cin >> 6;                 // K-steps per tap
+
+  int a_i0[4], a_i1[4], a_i2[4];              // conv: img, iy0, ix0 | temporal: frame, -, - | row m
+  bool a_in[4];
+  int schunk_a[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 32 + i * 8 + lrow;
+    const int m = tile_m * BM + r;
+    a_in[i] = m < p.m;
+    schunk_a[i] = (lchunk ^ ((r >> 1) & 7)) * 8;  // source chunk (halves) for this LDS slot
+    if (p.mode == SP_A_CONV3X3) {
+      const int per_img = p.hout * p.wout;
+      const int img = m / per_img;
+      const int rem = m - img * per_img;
+      const int oy = rem / p.wout;
+      a_i0[i] = img;
+      a_i1[i] = oy * p.stride - 1;
+      a_i2[i] = (rem - oy * p.wout) * p.stride - 1;
+    } else if (p.mode == SP_A_TEMPORAL3) {
+      a_i0[i] = (int)((m / p.hw) % p.frames);
+      a_i1[i] = 0;
+      a_i2[i] = m;
+    } else {
+      a_i0[i] = a_i1[i] = 0;
+      a_i2[i] = m;
+    }
+  }
+  const f16 *aptr[4];
+  int astep[4];
+  auto set_tap = [&](int tap) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int64_t row = -1;
+      if (a_in[i]) {
+        if (p.mode == SP_A_CONV3X3) {
+          const int ky = tap / 3, kx = tap - ky * 3;
+          const int iy = a_i1[i] + ky, ix = a_i2[i] + kx;
+          const int hv = p.hin << p.ups, wv = p.win << p.ups;
+          if (iy >= 0 && iy < hv && ix >= 0 && ix < wv)
+            row = ((int64_t)a_i0[i] * p.hin + (iy >> p.ups)) * p.win + (ix >> p.ups);
+        } else if (p.mode == SP_A_TEMPORAL3) {
+          const int f = a_i0[i] + tap - 1;
+          if (f >= 0 && f < p.frames) row = (int64_t)a_i2[i] + (int64_t)(tap - 1) * p.hw;
+        } else {
+          row = a_i2[i];
+        }
+      }
+      if (row >= 0) {
+        aptr[i] = p.a + row * p.lda + schunk_a[i];
+        astep[i] = BK;
+      } else {
+        aptr[i] = (const f16 *)(p.zero + lchunk * 16);
+        astep[i] = 0;
+      }
+    }
+  };
+
+  const f16 *bptr[B_LOADS];
+#pragma unroll
+  for (int j = 0; j < B_LOADS; ++j) {
+    const int r = wave * (BN / 4) + j * 8 + lrow;
+    const int n = tile_n * BN + r;
+    bptr[j] = p.w + (int64_t)n * p.k + (lchunk ^ ((r >> 1) & 7)) * 8;
+  }
+
+  auto stage = [&](int buf) {
+    char *sa = smem + buf * STAGE;
+    char *sb = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(aptr[i], sa + (wave * 32 + i * 8) * 128);
+      aptr[i] += astep[i];
+    }
+#pragma unroll
+    for (int j = 0; j < B_LOADS; ++j) {
+      glds16(bptr[j], sb + (wave * (BN / 4) + j * 8) * 128);
+      bptr[j] += BK;
+    }
+  };
+
+  // ---------------------------------------------------------------- main loop
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.k >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  // fragment byte offsets inside a stage (row*128 + swizzled chunk), chunk = ks*4 + fq
+  int offw[TN], offa[TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) offw[i] = (wn * (BN / 2) + i * 16 + fr) * 128;
+#pragma unroll
+  for (int j = 0; j < TM; ++j) offa[j] = (wm * 64 + j * 16 + fr) * 128;
+  // (row>>1)&7 of the fragment rows: rows are base16 + fr with base16 % 16 == 0
+  const int swz = (fr >> 1) & 7;
+
+  set_tap(0);
+  stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cur = 0;
+  int in_tap = 1;  // K-steps already staged within the current tap
+  int tap = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      if (in_tap == cpt) {
+        ++tap;
+        in_tap = 0;
+        set_tap(tap);
+      }
+      stage(cur ^ 1);
+      ++in_tap;
+    }
+    const char *sa = smem + cur * STAGE;
+    const char *sb = sa + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((ks * 4 + fq) ^ swz) << 4;
+      f16x8 fw[TN], fa[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fw[i] = *(const f16x8 *)(sb + offw[i] + coff);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) fa[j] = *(const f16x8 *)(sa + offa[j] + coff);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // acc[i][j][r]: n = tile_n*BN + wn*BN/2 + i*16 + 4*fq + r ; m = tile_m*BM + wm*64 + j*16 + fr
+  constexpr int BNO_FULL = BN;
+  const int bno = p.geglu ? BN / 2 : BNO_FULL;   // output columns of this tile
+  const int ldc = bno + 8;                        // halves, padded
+  f16 *sc = (f16 *)smem;
+
+  if (!p.geglu) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int nl = wn * (BN / 2) + i * 16 + 4 * fq;
+      const int n = tile_n * BN + nl;
+      f32x4 b = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) b = *(const f32x4 *)(p.bias + n);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int ml = wm * 64 + j * 16 + fr;
+        f32x4 v = acc[i][j] + b;
+        if (p.bias2) {
+          const int64_t m = (int64_t)tile_m * BM + ml;
+          const int64_t brow = m < p.m ? m / p.bias2_rows : 0;
+          v += *(const f32x4 *)(p.bias2 + brow * p.n + n);
+        }
+        v *= p.oscale;
+        f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        *(f16x4 *)(sc + ml * ldc + nl) = h;
+      }
+    }
+  } else {
+    if constexpr (TN % 2 == 0 && (BN / 2) % 32 == 0) {
+#pragma unroll
+      for (int i = 0; i < TN; i += 2) {
+        const int nl = wn * (BN / 2) + i * 16 + 4 * fq;   // h rows; gate rows are nl + 16
+        const int n = tile_n * BN + nl;
+        f32x4 bh = {0.f, 0.f, 0.f, 0.f}, bg = bh;
+        if (p.bias) {
+          bh = *(const f32x4 *)(p.bias + n);
+          bg = *(const f32x4 *)(p.bias + n + 16);
+        }
+        const int ol = (wn * (BN / 2) + i * 16) / 2 + 4 * fq;  // output column within tile
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int ml = wm * 64 + j * 16 + fr;
+          const f32x4 hv = acc[i][j] + bh, gv = acc[i + 1][j] + bg;
+          f16x4 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = (f16)(p.oscale * hv[r] * gelu_f(gv[r]));
+          *(f16x4 *)(sc + ml * ldc + ol) = h;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int cpr = bno >> 3;                        // 16-byte chunks per output row
+  const int ncols_total = p.geglu ? p.n / 2 : p.n;
+  const int nstore = p.n_store > 0 ? p.n_store : ncols_total;
+  for (int idx = tid; idx < BM * cpr; idx += THREADS) {
+    const int r = idx / cpr, c = idx - r * cpr;
+    const int64_t m = (int64_t)tile_m * BM + r;
+    if (m >= p.m) continue;
+    const int col = tile_n * bno + c * 8;
+    if (col >= nstore) continue;
+    f16x8 v = *(const f16x8 *)(sc + r * ldc + c * 8);
+    if (p.res1 || p.res2) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+      if (p.res1) {
+        const f16x8 q = *(const f16x8 *)(p.res1 + m * p.ldr1 + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += p.r1scale * (float)q[e];
+      }
+      if (p.res2) {
+        const f16x8 q = *(const f16x8 *)(p.res2 + m * p.ldr2 + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += p.r2scale * (float)q[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (f16)f[e];
+    }
+    if (col + 8 <= nstore) {
+      *(f16x8 *)(p.d + m * p.ldd + col) = v;
+    } else {
+      for (int e = 0; e < nstore - col; ++e) p.d[m * p.ldd + col + e] = v[e];
+    }
+  }
+}
+
+template <int BN>
+int launch(const GemmArgs &a, hipStream_t s) {
+  constexpr size_t lds = 2 * (BM * BK * 2 + BN * BK * 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)gemm_f16_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_f16_kernel<BN>, dim3(a.tiles_m * a.tiles_n), dim3(THREADS), lds, s, a);
+  SP_CHECK_LAUNCH("sp_gemm_f16");
+  return SP_OK;
+}
+
+}  // namespace
+
+extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
+  SP_REQUIRE(d != nullptr, "sp_gemm_f16: null descriptor");
+  SP_REQUIRE(d->a && d->w && d->d && d->zero_page, "sp_gemm_f16: null a/w/d/zero_page");
+  SP_REQUIRE(d->m > 0 && d->n > 0, "sp_gemm_f16: m,n must be positive (m=%d n=%d)", d->m, d->n);
+  SP_REQUIRE(d->cin > 0 && d->cin % 64 == 0, "sp_gemm_f16: cin=%d must be a multiple of 64", d->cin);
+  SP_REQUIRE(d->n % 64 == 0, "sp_gemm_f16: n=%d must be a multiple of 64", d->n);
+  SP_REQUIRE(d->mode >= SP_A_LINEAR && d->mode <= SP_A_TEMPORAL3, "sp_gemm_f16: bad mode %d", d->mode);
+  SP_REQUIRE(d->lda >= d->cin && d->lda % 8 == 0, "sp_gemm_f16: lda=%lld invalid", (long long)d->lda);
+  SP_REQUIRE(d->ldd % 8 == 0 || d->n_store > 0, "sp_gemm_f16: ldd must be a multiple of 8");
+  GemmArgs a{};
+  a.a = (const f16 *)d->a; a.w = (const f16 *)d->w; a.bias = d->bias; a.bias2 = d->bias2;
+  a.res1 = (const f16 *)d->res1; a.res2 = (const f16 *)d->res2; a.d = (f16 *)d->d;
+  a.zero = (const char *)d->zero_page;
+  a.lda = d->lda; a.ldr1 = d->ldr1; a.ldr2 = d->ldr2; a.ldd = d->ldd;
+  a.mode = d->mode; a.cin = d->cin;
+  a.taps = d->mode == SP_A_CONV3X3 ? 9 : d->mode == SP_A_TEMPORAL3 ? 3 : 1;
+  a.m = d->m; a.n = d->n; a.k = a.taps * d->cin;
+  a.oscale = d->oscale; a.r1scale = d->r1scale; a.r2scale = d->r2scale;
+  a.geglu = d->geglu; a.n_store = d->n_store;
+  a.bias2_rows = d->bias2_rows > 0 ? d->bias2_rows : d->m;
+  if (d->res1) SP_REQUIRE(d->ldr1 % 8 == 0, "sp_gemm_f16: ldr1 must be a multiple of 8");
+  if (d->res2) SP_REQUIRE(d->ldr2 % 8 == 0, "sp_gemm_f16: ldr2 must be a multiple of 8");
+  if (d->mode == SP_A_CONV3X3) {
+    SP_REQUIRE(d->stride == 1 || d->stride == 2, "sp_gemm_f16: stride must be 1 or 2");
+    SP_REQUIRE(d->n_img > 0 && d->hin > 0 && d->win > 0 && d->hout > 0 && d->wout > 0,
+               "sp_gemm_f16: conv geometry must be positive");
+    const int hv = d->hin << (d->upsample2x ? 1 : 0), wv = d->win << (d->upsample2x ? 1 : 0);
+    SP_REQUIRE(d->hout == (hv + 2 - 3) / d->stride + 1 && d->wout == (wv + 2 - 3) / d->stride + 1,
+               "sp_gemm_f16: conv output %dx%d inconsistent with input %dx%d stride %d", d->hout,
+               d->wout, hv, wv, d->stride);
+    SP_REQUIRE((int64_t)d->n_img * d->hout * d->wout == d->m, "sp_gemm_f16: m != n_img*hout*wout");
+    a.n_img = d->n_img; a.hin = d->hin; a.win = d->win; a.hout = d->hout; a.wout = d->wout;
+    a.stride = d->stride; a.ups = d->upsample2x ? 1 : 0;
+  } else if (d->mode == SP_A_TEMPORAL3) {
+    SP_REQUIRE(d->frames > 0 && d->hw > 0 && d->m % (d->frames * d->hw) == 0,
+               "sp_gemm_f16: temporal geometry: m=%d frames=%d hw=%lld", d->m, d->frames,
+               (long long)d->hw);
+    a.frames = d->frames; a.hw = d->hw;
+  }
+  if (d->geglu) SP_REQUIRE(d->n % 128 == 0, "sp_gemm_f16: geglu needs n %% 128 == 0");
+  a.tiles_m = (d->m + BM - 1) / BM;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->n % 128 == 0) { a.tiles_n = d->n / 128; return launch<128>(a, s); }
+  if (d->n % 160 == 0) { a.tiles_n = d->n / 160; return launch<160>(a, s); }
+  a.tiles_n = d->n / 64;
+  return launch<64>(a, s);
+}

@@ -1,0 +1,234 @@
+// GroupNorm(+SiLU) and LayerNorm for channels-last fp16 token matrices (HBM-bound kernels).
+//
+// GroupNorm: two launches.
+//   stats : grid (instances, splits); every thread owns one 8-channel octet (16-byte loads, rows
+//           strided by P), accumulates per-channel sum / sum-of-squares in fp32 registers, the block
+//           reduces them in LDS in a FIXED order (deterministic, no atomics) to per-group partials
+//           and writes [instance][split][group][2].
+//   apply : each block first folds the `splits` partials of its instance (fixed order, fp64 for the
+//           variance), then streams rows: y = x*scale[c] + shift[c], optional SiLU, 16-byte stores.
+// The second read of x is served mostly by the 256 MiB Infinity Cache (tensors are <= 83 MB).
+#include "common.h"
+
+namespace {
+
+__host__ __device__ inline int gn_rows_per_iter(int oc) { int p = 512 / oc; return p < 1 ? 1 : p; }
+
+__global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ part, int64_t rows,
+                                int c, int groups, int splits) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *sh = (float *)smem;                      // [P][C][2]
+  const int oc = c >> 3;
+  const int P = gn_rows_per_iter(oc);
+  const int tid = threadIdx.x;
+  const int o = tid % oc, pr = tid / oc;
+  const int inst = blockIdx.x, split = blockIdx.y;
+  const int64_t per = (rows + splits - 1) / splits;
+  const int64_t r0 = (int64_t)split * per;
+  int64_t r1 = r0 + per; if (r1 > rows) r1 = rows;
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+  const f16 *base = x + ((int64_t)inst * rows) * c + o * 8;
+  if (pr < P) {
+    for (int64_t r = r0 + pr; r < r1; r += P) {
+      const f16x8 v = *(const f16x8 *)(base + r * c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; ss[e] += f * f; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sh[((pr * c) + o * 8 + e) * 2 + 0] = s[e];
+      sh[((pr * c) + o * 8 + e) * 2 + 1] = ss[e];
+    }
+  }
+  __syncthreads();
+  if (tid < groups) {
+    const int cpg = c / groups;
+    float a = 0.f, b = 0.f;
+    for (int q = 0; q < P; ++q)
+      for (int ch = tid * cpg; ch < (tid + 1) * cpg; ++ch) {
+        a += sh[(q * c + ch) * 2 + 0];
+        b += sh[(q * c + ch) * 2 + 1];
+      }
+    float *dst = part + (((int64_t)inst * splits + split) * groups + tid) * 2;
+    dst[0] = a; dst[1] = b;
+  }
+}
+
+__global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restrict__ part,
+                                const float *__restrict__ gamma, const float *__restrict__ beta,
+                                f16 *__restrict__ y, int64_t rows, int c, int groups, int splits,
+                                float eps, int silu, int64_t rows_per_block) {
+  __shared__ float sh_mean[64], sh_rstd[64];
+  const int oc = c >> 3;
+  const int P = gn_rows_per_iter(oc);
+  const int tid = threadIdx.x;
+  const int inst = blockIdx.x;
+  if (tid < groups) {
+    double a = 0.0, b = 0.0;
+    const float *src = part + ((int64_t)inst * splits * groups + tid) * 2;
+    for (int sp = 0; sp < splits; ++sp) { a += src[(int64_t)sp * groups * 2]; b += src[(int64_t)sp * groups * 2 + 1]; }
+    const double cnt = (double)rows * (c / groups);
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean; if (var < 0.0) var = 0.0;
+    sh_mean[tid] = (float)mean;
+    sh_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int o = tid % oc, pr = tid / oc;
+  if (pr >= P) return;
+  const int cpg = c / groups;
+  float sc[8], sf[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = o * 8 + e;
+    const int g = ch / cpg;
+    const float ga = gamma ? gamma[ch] : 1.f, be = beta ? beta[ch] : 0.f;
+    sc[e] = sh_rstd[g] * ga;
+    sf[e] = be - sh_mean[g] * sc[e];
+  }
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
+  const f16 *xb = x + ((int64_t)inst * rows) * c + o * 8;
+  f16 *yb = y + ((int64_t)inst * rows) * c + o * 8;
+  for (int64_t r = r0 + pr; r < r1; r += P) {
+    const f16x8 v = *(const f16x8 *)(xb + r * c);
+    f16x8 w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = (float)v[e] * sc[e] + sf[e];
+      if (silu) f = silu_f(f);
+      w[e] = (f16)f;
+    }
+    *(f16x8 *)(yb + r * c) = w;
+  }
+}
+
+int gn_splits(int instances, int64_t rows, int P) {
+  int64_t want = (2048 + instances - 1) / instances;
+  int64_t maxs = rows / (4 * (int64_t)P); if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want > 512) want = 512;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+// ---------------------------------------------------------------------------------- LayerNorm
+// one wave per row; lane owns 8-channel octets lane, lane+64, ... (C/8 <= 64*NV)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_kernel(const f16 *__restrict__ x, const f16 *__restrict__ addvec,
+                                                 int64_t addvec_rows, f16 *__restrict__ sum_out,
+                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                 f16 *__restrict__ y, int64_t rows, int c, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int oc = c >> 3;
+  float v[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int o = lane + i * 64;
+    if (o < oc) {
+      f16x8 q = *(const f16x8 *)(x + row * c + o * 8);
+      if (addvec) {
+        const f16x8 a = *(const f16x8 *)(addvec + (row / addvec_rows) * c + o * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = (f16)((float)q[e] + (float)a[e]);
+        if (sum_out) *(f16x8 *)(sum_out + row * c + o * 8) = q;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = (float)q[e]; s += v[i][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)c;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int o = lane + i * 64;
+    if (o < oc) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)c + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int o = lane + i * 64;
+    if (o < oc) {
+      const f32x4 g0 = *(const f32x4 *)(gamma + o * 8), g1 = *(const f32x4 *)(gamma + o * 8 + 4);
+      const f32x4 b0 = *(const f32x4 *)(beta + o * 8), b1 = *(const f32x4 *)(beta + o * 8 + 4);
+      f16x8 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        w[e] = (f16)((v[i][e] - mean) * rstd * g0[e] + b0[e]);
+        w[e + 4] = (f16)((v[i][e + 4] - mean) * rstd * g1[e] + b1[e]);
+      }
+      *(f16x8 *)(y + row * c + o * 8) = w;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t sp_groupnorm_ws_bytes(int instances, int64_t rows, int c, int groups) {
+  if (instances <= 0 || rows <= 0 || c <= 0 || groups <= 0) return 0;
+  return (size_t)instances * 512 * groups * 2 * sizeof(float);
+}
+
+extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *beta, void *y,
+                                int instances, int64_t rows, int c, int groups, float eps,
+                                int fuse_silu, void *ws, size_t ws_bytes, void *stream) {
+  SP_REQUIRE(x && y && ws, "sp_groupnorm_f16: null pointer");
+  SP_REQUIRE(instances > 0 && rows > 0, "sp_groupnorm_f16: instances/rows must be positive");
+  SP_REQUIRE(c % 8 == 0 && c >= 8 && c <= 4096, "sp_groupnorm_f16: C=%d must be a multiple of 8 in [8,4096]", c);
+  SP_REQUIRE(groups > 0 && groups <= 64 && c % groups == 0, "sp_groupnorm_f16: groups=%d invalid for C=%d", groups, c);
+  SP_REQUIRE(ws_bytes >= sp_groupnorm_ws_bytes(instances, rows, c, groups), "sp_groupnorm_f16: workspace too small");
+  const int oc = c / 8;
+  const int P = gn_rows_per_iter(oc);
+  const int threads = ((oc * P + 63) / 64) * 64 < 64 ? 64 : ((oc * P + 63) / 64) * 64;
+  SP_REQUIRE(threads <= 1024, "sp_groupnorm_f16: C too large");
+  const int splits = gn_splits(instances, rows, P);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)P * c * 2 * sizeof(float);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(instances, splits), dim3(threads), lds, s, (const f16 *)x,
+                     (float *)ws, rows, c, groups, splits);
+  SP_CHECK_LAUNCH("sp_groupnorm_f16(stats)");
+  int64_t blocks_y = (2048 + instances - 1) / instances;
+  int64_t maxb = (rows + 4 * P - 1) / (4 * P);
+  if (blocks_y > maxb) blocks_y = maxb;
+  if (blocks_y < 1) blocks_y = 1;
+  const int64_t rpb = (rows + blocks_y - 1) / blocks_y;
+  blocks_y = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(instances, (unsigned)blocks_y), dim3(threads), 0, s,
+                     (const f16 *)x, (const float *)ws, gamma, beta, (f16 *)y, rows, c, groups, splits,
+                     eps, fuse_silu, rpb);
+  SP_CHECK_LAUNCH("sp_groupnorm_f16(apply)");
+  return SP_OK;
+}
+
+extern "C" int sp_layernorm_f16(const void *x, const void *addvec, int64_t addvec_rows, void *sum_out,
+                                const float *gamma, const float *beta, void *y, int64_t rows, int c,
+                                float eps, void *stream) {
+  SP_REQUIRE(x && y && gamma && beta, "sp_layernorm_f16: null pointer");
+  SP_REQUIRE(rows > 0 && c % 8 == 0 && c >= 8 && c <= 2048, "sp_layernorm_f16: rows=%lld C=%d unsupported",
+             (long long)rows, c);
+  if (addvec) SP_REQUIRE(addvec_rows > 0, "sp_layernorm_f16: addvec_rows must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  const int oc = c / 8;
+#define LN_LAUNCH(NV)                                                                              \
+  hipLaunchKernelGGL(ln_kernel<NV>, dim3(grid), dim3(256), 0, s, (const f16 *)x, (const f16 *)addvec, \
+                     addvec_rows > 0 ? addvec_rows : 1, (f16 *)sum_out, gamma, beta, (f16 *)y, rows, c, eps)
+  if (oc <= 64) LN_LAUNCH(1);
+  else if (oc <= 128) LN_LAUNCH(2);
+  else if (oc <= 192) LN_LAUNCH(3);
+  else LN_LAUNCH(4);
+#undef LN_LAUNCH
+  SP_CHECK_LAUNCH("sp_layernorm_f16");
+  return SP_OK;
+}

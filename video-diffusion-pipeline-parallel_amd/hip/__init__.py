@@ -1,0 +1,75 @@
+"""ctypes binding of ``libsvdpipe_hip.so`` (C ABI declared in ``include/svdpipe.h``).
+
+The shared object is built in-tree by ``csrc/Makefile`` (``__graft_entry__.build()``).  There is
+no fallback: importing :mod:`ops` without the library raises ``RuntimeError``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvdpipe_hip.so")
+_lib = None
+
+
+class GemmDesc(ctypes.Structure):
+    """Mirror of ``struct sp_gemm_desc`` (include/svdpipe.h)."""
+
+    _fields_ = [
+        ("a", ctypes.c_void_p), ("lda", ctypes.c_int64), ("mode", ctypes.c_int), ("cin", ctypes.c_int),
+        ("n_img", ctypes.c_int), ("hin", ctypes.c_int), ("win", ctypes.c_int), ("hout", ctypes.c_int),
+        ("wout", ctypes.c_int), ("stride", ctypes.c_int), ("upsample2x", ctypes.c_int),
+        ("frames", ctypes.c_int), ("hw", ctypes.c_int64),
+        ("w", ctypes.c_void_p), ("m", ctypes.c_int), ("n", ctypes.c_int),
+        ("bias", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("bias2_rows", ctypes.c_int64),
+        ("res1", ctypes.c_void_p), ("ldr1", ctypes.c_int64), ("r1scale", ctypes.c_float),
+        ("res2", ctypes.c_void_p), ("ldr2", ctypes.c_int64), ("r2scale", ctypes.c_float),
+        ("oscale", ctypes.c_float), ("geglu", ctypes.c_int), ("n_store", ctypes.c_int),
+        ("d", ctypes.c_void_p), ("ldd", ctypes.c_int64), ("zero_page", ctypes.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/svdpipe.h
+_P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+SIGNATURES = {
+    "sp_last_error": (ctypes.c_char_p, []),
+    "sp_version": (_I, []),
+    "sp_gemm_f16": (_I, [ctypes.POINTER(GemmDesc), _P]),
+    "sp_gemv_f16": (_I, [_P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "sp_sinusoid_f16": (_I, [_P, _P, _I, _I, _P]),
+    "sp_groupnorm_ws_bytes": (_Z, [_I, _L, _I, _I]),
+    "sp_groupnorm_f16": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _Z, _P]),
+    "sp_layernorm_f16": (_I, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _F, _P]),
+    "sp_attn_spatial_f16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _P]),
+    "sp_attn_temporal_f16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _L, _I, _F, _P, _P]),
+    "sp_pack_input_f16": (_I, [_P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
+    "sp_euler_step_f16": (_I, [_P, _P, _P, _L, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
+    "sp_concat_channels_f16": (_I, [_P, _I, _P, _I, _P, _L, _P]),
+    "sp_add_rowvec_f16": (_I, [_P, _P, _P, _L, _I, _P]),
+    "sp_dummy_unet_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _F, _I, _I, _I, _I, _I, _I, _P]),
+}
+
+
+def load():
+    """Load the library once and attach prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C csrc`). "
+                "There is no CPU/PyTorch fallback for the GPU path."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return load().sp_last_error().decode()

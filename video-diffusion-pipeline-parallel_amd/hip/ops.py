@@ -1,0 +1,145 @@
+"""Tensor-level wrappers over the C ABI: raw ``data_ptr()`` + the current HIP stream go in,
+kernels are enqueued, nothing is synchronised.  PyTorch only owns the memory."""
+
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import GemmDesc, last_error, load
+
+A_LINEAR, A_CONV3X3, A_TEMPORAL3 = 0, 1, 2
+ZERO_PAGE_BYTES = 4096
+_zero_pages: dict = {}
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise HipKernelError(f"{what} failed (rc={rc}): {last_error()}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def zero_page(device) -> torch.Tensor:
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _zero_pages:
+        _zero_pages[key] = torch.zeros(ZERO_PAGE_BYTES, dtype=torch.uint8, device=dev)
+    return _zero_pages[key]
+
+
+def _f16(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float16 or not t.is_cuda:
+        raise TypeError(f"{name} must be a float16 tensor on a HIP device")
+    return t
+
+
+def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=None, bias=None,
+         bias2=None, bias2_rows=0, res1=None, r1scale=1.0, res2=None, r2scale=1.0, oscale=1.0,
+         geglu=False, n_store=0, ldd=None, ldr1=None, ldr2=None):
+    """``out[m][:] = epilogue(sum_taps A_tap @ W^T)``; see ``sp_gemm_desc`` in include/svdpipe.h."""
+    d = GemmDesc()
+    d.a, d.lda, d.mode, d.cin = _f16(a, "a").data_ptr(), int(lda if lda is not None else cin), mode, cin
+    if mode == A_CONV3X3:
+        d.n_img, d.hin, d.win, d.hout, d.wout, d.stride, d.upsample2x = conv
+    if mode == A_TEMPORAL3:
+        d.frames, d.hw = temporal
+    d.w, d.m, d.n = _f16(w, "w").data_ptr(), m, n
+    d.bias, d.bias2, d.bias2_rows = _ptr(bias), _ptr(bias2), bias2_rows
+    nout = n // 2 if geglu else n
+    d.res1, d.ldr1, d.r1scale = _ptr(res1), int(ldr1 if ldr1 is not None else nout), r1scale
+    d.res2, d.ldr2, d.r2scale = _ptr(res2), int(ldr2 if ldr2 is not None else nout), r2scale
+    d.oscale, d.geglu, d.n_store = oscale, int(geglu), n_store
+    d.d, d.ldd = _f16(out, "out").data_ptr(), int(ldd if ldd is not None else (n_store or nout))
+    d.zero_page = zero_page(a.device).data_ptr()
+    _check(load().sp_gemm_f16(ctypes.byref(d), _stream()), "sp_gemm_f16")
+    return out
+
+
+def gemv(x, w, b, *, n, k, rows=1, ldx=None, y32=None, y16=None, ldy=None, silu_in=False, silu_out=False):
+    _check(load().sp_gemv_f16(_f16(x, "x").data_ptr(), int(ldx if ldx is not None else k), _f16(w, "w").data_ptr(),
+                              _ptr(b), _ptr(y32), _ptr(y16), int(ldy if ldy is not None else n), rows, n, k,
+                              int(silu_in), int(silu_out), _stream()), "sp_gemv_f16")
+
+
+def sinusoid(values32, out16, count, dim):
+    _check(load().sp_sinusoid_f16(values32.data_ptr(), out16.data_ptr(), count, dim, _stream()), "sp_sinusoid_f16")
+
+
+def groupnorm_ws_bytes(instances, rows, c, groups) -> int:
+    return int(load().sp_groupnorm_ws_bytes(instances, rows, c, groups))
+
+
+def groupnorm(x, gamma, beta, y, *, instances, rows, c, groups, eps, silu, ws):
+    _check(load().sp_groupnorm_f16(_f16(x, "x").data_ptr(), _ptr(gamma), _ptr(beta), _f16(y, "y").data_ptr(),
+                                   instances, rows, c, groups, eps, int(silu), ws.data_ptr(),
+                                   ws.numel() * ws.element_size(), _stream()), "sp_groupnorm_f16")
+    return y
+
+
+def layernorm(x, gamma, beta, y, *, rows, c, eps=1e-5, addvec=None, addvec_rows=0, sum_out=None):
+    _check(load().sp_layernorm_f16(_f16(x, "x").data_ptr(), _ptr(addvec), addvec_rows, _ptr(sum_out),
+                                   gamma.data_ptr(), beta.data_ptr(), _f16(y, "y").data_ptr(), rows, c, eps,
+                                   _stream()), "sp_layernorm_f16")
+    return y
+
+
+def attn_spatial(q, k, v, o, *, ldq, ldk, ldv, ldo, batch, seq, heads, scale=0.125):
+    _check(load().sp_attn_spatial_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), ldq, ldk, ldv, ldo,
+                                      batch, seq, heads, scale, zero_page(o.device).data_ptr(), _stream()),
+           "sp_attn_spatial_f16")
+    return o
+
+
+def attn_temporal(q, k, v, o, *, ldq, ldk, ldv, ldo, batch, frames, hw, heads, scale=0.125):
+    _check(load().sp_attn_temporal_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), ldq, ldk, ldv, ldo,
+                                       batch, frames, hw, heads, scale, zero_page(o.device).data_ptr(), _stream()),
+           "sp_attn_temporal_f16")
+    return o
+
+
+def pack_input(latent, image_latents, out, *, in_scale, b, frames, h, w, cpad):
+    _check(load().sp_pack_input_f16(_f16(latent, "latent").data_ptr(), _f16(image_latents, "image_latents").data_ptr(),
+                                    out.data_ptr(), in_scale, b, frames, h, w, cpad, _stream()), "sp_pack_input_f16")
+    return out
+
+
+def euler_step(latent, eps_cond, eps_uncond, guidance, out, *, ld_eps, sigma, sigma_next, b, frames, h, w):
+    _check(load().sp_euler_step_f16(latent.data_ptr(), eps_cond.data_ptr(), _ptr(eps_uncond), ld_eps, _ptr(guidance),
+                                    out.data_ptr(), sigma, sigma_next, b, frames, h, w, _stream()), "sp_euler_step_f16")
+    return out
+
+
+def concat_channels(a, ca, b, cb, out, rows):
+    _check(load().sp_concat_channels_f16(a.data_ptr(), ca, b.data_ptr(), cb, out.data_ptr(), rows, _stream()),
+           "sp_concat_channels_f16")
+    return out
+
+
+def add_rowvec(x, vec32, y, rows, c):
+    _check(load().sp_add_rowvec_f16(x.data_ptr(), vec32.data_ptr(), y.data_ptr(), rows, c, _stream()), "sp_add_rowvec_f16")
+    return y
+
+
+def dummy_unet_forward(x, w1, b1, w2, b2, ln_w, ln_b, gain, ln_eps):
+    """DummyUNet forward on a HIP device (fp32, (B,C,F,H,W)); see csrc/dummy_unet.hip."""
+    B, C, F, H, W = x.shape
+    hidden_c = w1.shape[0]
+    out = torch.empty_like(x)
+    hidden = torch.empty((B, hidden_c, F, H, W), dtype=torch.float32, device=x.device)
+    _check(load().sp_dummy_unet_f32(x.data_ptr(), out.data_ptr(), hidden.data_ptr(), w1.contiguous().data_ptr(),
+                                    b1.data_ptr(), w2.contiguous().data_ptr(), b2.data_ptr(), _ptr(ln_w), _ptr(ln_b),
+                                    float(ln_eps), int(ln_w is not None), float(gain), B, C, hidden_c, F, H, W,
+                                    _stream()), "sp_dummy_unet_f32")
+    return out

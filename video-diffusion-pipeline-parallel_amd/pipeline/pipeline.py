@@ -1,0 +1,332 @@
+"""Per-rank stage executor of the diffusion-step pipeline.
+
+API mirror of ``/root/reference/src/pipeline/pipeline.py`` (symbol -> reference lines):
+
+  ``LatentSpec``                 ``:25-34``     ``PipelineStage.run``            ``:100-111``
+  ``PipelineConfig``             ``:37-48``     ``PipelineStage.run_many``       ``:113-132``
+  ``PipelineStage.__init__``     ``:57-70``     ``_process_single_latent``       ``:134-157``
+  ``_recv_latent/_send_latent``  ``:75-84``     ``run_single_latent``            ``:160-185``
+  ``_run_local_steps``           ``:86-98``     ``run_pipeline_latents``         ``:188-208``
+
+Same arguments, same return values, same ``ValueError`` / ``RuntimeError`` conditions, same
+``[rank=N] ...`` INFO log prefix, and the same quirk that the *timestep value* is what gets
+passed to ``model(latent, step)`` (ref ``:87-95``).
+
+What is different is the transport on a GPU rank.  The reference blocks the host in
+``dist.send`` / ``dist.recv`` on the compute stream.  Here, when the latent lives on a HIP
+device, hand-offs go over RCCL point-to-point (``torch.distributed`` backend ``"nccl"`` on ROCm)
+from a dedicated side stream:
+
+* send: an event is recorded on the compute stream after the last local step, the side
+  stream waits on it and issues ``isend``; the compute stream is free to start the next
+  sample's first UNet step immediately.
+* recv: ``run_many`` pre-posts the ``irecv`` of sample ``i+1`` into the second half of a
+  double buffer while sample ``i`` computes; the compute stream only waits on the event that
+  marks its own latent as landed.
+
+No collective is involved; one 1-2 MB message per stage boundary per sample travels over the
+xGMI link between neighbouring ranks.  CPU / Gloo ranks (the simulator path) keep the
+reference's blocking behaviour, which is what the golden vectors in ``tests/golden`` pin.
+
+Extension field (not in the reference): ``PipelineConfig.balanced`` selects
+``assign_steps_balanced`` so 25 steps can be split over 2/4/8 ranks.
+"""
+
+from __future__ import annotations
+
+import logging
+import time
+from collections import deque
+from collections.abc import Sequence
+from dataclasses import dataclass
+from typing import Callable, Deque, Optional
+
+import torch
+import torch.distributed as dist
+
+from .step_assignment import StepRange, assign_steps, assign_steps_balanced
+
+LOGGER = logging.getLogger(__name__)
+
+
+@dataclass(frozen=True)
+class LatentSpec:
+    """Shape / dtype / device of the latent every stage boundary carries."""
+
+    shape: torch.Size
+    dtype: torch.dtype
+    device: torch.device
+
+    def empty(self) -> torch.Tensor:
+        return torch.empty(self.shape, dtype=self.dtype, device=self.device)
+
+
+@dataclass(frozen=True)
+class PipelineConfig:
+    total_steps: int
+    world_size: int
+    rank: int
+    timesteps: Sequence[int]
+    latent_spec: LatentSpec
+    send_tag: int = 0
+    # --- extensions beyond the reference dataclass -------------------------------------
+    balanced: bool = False          # use assign_steps_balanced (uneven contiguous split)
+    async_comm: Optional[bool] = None  # None = auto (side-stream RCCL when latent is on a GPU)
+
+    def __post_init__(self) -> None:
+        if len(self.timesteps) != self.total_steps:
+            raise ValueError("len(timesteps) must equal total_steps.")
+
+
+InputSupplier = Callable[[int], torch.Tensor]
+
+
+class _SideStreamLink:
+    """RCCL send/recv on a side HIP stream, fenced against the compute stream by events.
+
+    Holds a two-slot receive ring so the next sample's latent can land while the current one
+    is still being denoised, and keeps sent tensors alive until their ``isend`` retires.
+    """
+
+    def __init__(self, spec: LatentSpec, rank: int, tag: int) -> None:
+        self.spec = spec
+        self.rank = rank
+        self.tag = tag
+        self.stream = torch.cuda.Stream(device=spec.device)
+        self._ring = [spec.empty(), spec.empty()]
+        self._slot = 0
+        self._pending = None  # (work, buffer) of a pre-posted irecv
+        self._in_flight: Deque[tuple] = deque()
+
+    # -- receive -------------------------------------------------------------------------
+    def post_recv(self) -> None:
+        if self._pending is not None:
+            return
+        buf = self._ring[self._slot]
+        self._slot ^= 1
+        with torch.cuda.stream(self.stream):
+            work = dist.irecv(buf, src=self.rank - 1, tag=self.tag)
+        self._pending = (work, buf)
+
+    def take(self) -> torch.Tensor:
+        """Return the next latent; the *compute* stream is made to wait for it, not the host."""
+
+        self.post_recv()
+        work, buf = self._pending
+        self._pending = None
+        with torch.cuda.stream(self.stream):
+            work.wait()  # stream-level dependency on the RCCL recv
+            landed = torch.cuda.Event()
+            landed.record(self.stream)
+        torch.cuda.current_stream(self.spec.device).wait_event(landed)
+        return buf
+
+    # -- send ----------------------------------------------------------------------------
+    def send(self, latent: torch.Tensor) -> None:
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.spec.device))
+        latent.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            work = dist.isend(latent, dst=self.rank + 1, tag=self.tag)
+        self._in_flight.append((work, latent))
+        while self._in_flight and self._in_flight[0][0].is_completed():
+            self._in_flight.popleft()
+
+    def drain(self) -> None:
+        while self._in_flight:
+            work, _ = self._in_flight.popleft()
+            work.wait()
+        self.stream.synchronize()
+
+
+class PipelineStage:
+    """Execution + hand-off behaviour of one rank (one pipeline stage)."""
+
+    def __init__(
+        self,
+        model,
+        config: PipelineConfig,
+        logger: logging.Logger | None = None,
+    ) -> None:
+        self.model = model
+        self.config = config
+        self.logger = logger or LOGGER
+        splitter = assign_steps_balanced if config.balanced else assign_steps
+        self.step_range: StepRange = splitter(
+            total_steps=config.total_steps,
+            world_size=config.world_size,
+            rank=config.rank,
+        )
+        use_async = config.async_comm
+        if use_async is None:
+            use_async = (
+                config.latent_spec.device.type == "cuda"
+                and config.world_size > 1
+                and dist.is_available()
+                and dist.is_initialized()
+                and dist.get_backend() == "nccl"
+            )
+        self._link: _SideStreamLink | None = (
+            _SideStreamLink(config.latent_spec, config.rank, config.send_tag) if use_async else None
+        )
+        self._more_samples_expected = False
+
+    # ------------------------------------------------------------------ logging
+    def _log(self, message: str) -> None:
+        self.logger.info("[rank=%s] %s", self.config.rank, message)
+
+    # ------------------------------------------------------------------ transport
+    def _recv_latent(self) -> torch.Tensor:
+        upstream = self.config.rank - 1
+        self._log(f"waiting for latent from rank {upstream}")
+        if self._link is not None:
+            tensor = self._link.take()
+            if self._more_samples_expected:
+                self._link.post_recv()
+        else:
+            tensor = self.config.latent_spec.empty()
+            dist.recv(tensor, src=upstream, tag=self.config.send_tag)
+        self._log("received latent")
+        return tensor
+
+    def _send_latent(self, latent: torch.Tensor) -> None:
+        downstream = self.config.rank + 1
+        self._log(f"sending latent to rank {downstream}")
+        if self._link is not None:
+            self._link.send(latent)
+        else:
+            dist.send(latent, dst=downstream, tag=self.config.send_tag)
+
+    # ------------------------------------------------------------------ compute
+    def _run_local_steps(self, latent: torch.Tensor) -> torch.Tensor:
+        owned = list(self.config.timesteps[self.step_range.start : self.step_range.end])
+        if len(owned) != self.step_range.count:
+            raise RuntimeError("Local timestep slice length mismatch with step range.")
+
+        verbose = self.logger.isEnabledFor(logging.INFO)
+        for step in owned:
+            began = time.time()
+            latent = self.model(latent, step)  # the timestep VALUE is the argument (ref :95)
+            if verbose:
+                self._log(f"step {step} completed in {(time.time() - began) * 1000.0:.2f} ms")
+        return latent
+
+    # ------------------------------------------------------------------ public entry points
+    def run(self, input_latent: torch.Tensor | None) -> torch.Tensor | None:
+        """One latent through this stage.  Rank 0 supplies it, other ranks pass ``None``.
+
+        Returns the final latent on the last rank and ``None`` elsewhere.
+        """
+
+        return self._process_single_latent(input_latent, sample_idx=None)
+
+    def run_many(
+        self,
+        num_samples: int,
+        *,
+        input_supplier: InputSupplier | None = None,
+    ) -> list[torch.Tensor] | None:
+        if num_samples <= 0:
+            raise ValueError("num_samples must be positive for pipeline execution")
+        first_rank = self.config.rank == 0
+        if first_rank and input_supplier is None:
+            raise ValueError("rank 0 requires an input_supplier when processing multiple samples")
+
+        finished: list[torch.Tensor] = []
+        for sample_idx in range(num_samples):
+            self._more_samples_expected = sample_idx + 1 < num_samples
+            result = self._process_single_latent(
+                input_supplier(sample_idx) if first_rank else None,
+                sample_idx=sample_idx,
+            )
+            if result is not None:
+                finished.append(result)
+        self._more_samples_expected = False
+        return finished or None
+
+    def _process_single_latent(
+        self, input_latent: torch.Tensor | None, sample_idx: int | None
+    ) -> torch.Tensor | None:
+        label = "" if sample_idx is None else f"sample {sample_idx} "
+        cfg = self.config
+
+        if cfg.rank == 0:
+            if input_latent is None:
+                raise ValueError("rank 0 requires an input latent tensor")
+            latent = input_latent.to(cfg.latent_spec.device)
+            self._log(f"{label}input prepared")
+        else:
+            if input_latent is not None:
+                raise ValueError("non-zero ranks should not receive an eager latent")
+            latent = self._recv_latent()
+            self._log(f"{label}received latent")
+
+        latent = self._run_local_steps(latent)
+
+        if cfg.rank == cfg.world_size - 1:
+            self._log(f"{label}final rank completed")
+            return latent
+
+        self._send_latent(latent)
+        return None
+
+    def drain(self) -> None:
+        """Wait for outstanding side-stream sends (no-op on the blocking transport)."""
+
+        if self._link is not None:
+            self._link.drain()
+
+
+def _make_stage(model, *, total_steps, timesteps, world_size, rank, latent_spec, logger,
+                balanced: bool = False) -> PipelineStage:
+    config = PipelineConfig(
+        total_steps=total_steps,
+        world_size=world_size,
+        rank=rank,
+        timesteps=timesteps,
+        latent_spec=latent_spec,
+        balanced=balanced,
+    )
+    return PipelineStage(model=model, config=config, logger=logger)
+
+
+def run_single_latent(
+    model,
+    *,
+    total_steps: int,
+    timesteps: Sequence[int],
+    world_size: int,
+    rank: int,
+    latent_spec: LatentSpec,
+    input_latent: torch.Tensor | None,
+    logger: logging.Logger | None = None,
+    balanced: bool = False,
+) -> torch.Tensor | None:
+    """All ranks call this once per latent; rank 0 passes the latent, the others ``None``."""
+
+    stage = _make_stage(model, total_steps=total_steps, timesteps=timesteps, world_size=world_size,
+                        rank=rank, latent_spec=latent_spec, logger=logger, balanced=balanced)
+    out = stage.run(input_latent=input_latent)
+    stage.drain()
+    return out
+
+
+def run_pipeline_latents(
+    model,
+    *,
+    total_steps: int,
+    timesteps: Sequence[int],
+    world_size: int,
+    rank: int,
+    latent_spec: LatentSpec,
+    num_samples: int,
+    input_supplier: InputSupplier | None,
+    logger: logging.Logger | None = None,
+    balanced: bool = False,
+) -> list[torch.Tensor] | None:
+    stage = _make_stage(model, total_steps=total_steps, timesteps=timesteps, world_size=world_size,
+                        rank=rank, latent_spec=latent_spec, logger=logger, balanced=balanced)
+    out = stage.run_many(num_samples, input_supplier=input_supplier)
+    stage.drain()
+    return out
