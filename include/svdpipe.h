@@ -68,8 +68,9 @@ typedef struct sp_gemm_desc {
      geglu!=0: out[m][j] = h*gelu(gate) over the interleaved column pairs, Nout = n/2
      (bias applies before gelu; oscale/res are applied to the product) */
   const float *bias;    /* [n] or NULL */
-  const float *bias2;   /* [nb][n] or NULL */
-  int64_t bias2_rows;   /* rows of D sharing one bias2 row (e.g. H*W of a frame) */
+  const float *bias2;   /* [nb][ldb2] or NULL */
+  int64_t bias2_rows;   /* rows of D sharing one bias2 row (e.g. frames*H*W of a batch item) */
+  int64_t ldb2;         /* floats between bias2 rows (0 = n) */
   const void *res1; int64_t ldr1; float r1scale;   /* fp16 [m][ldr1] or NULL */
   const void *res2; int64_t ldr2; float r2scale;
   float oscale;

@@ -33,7 +33,7 @@ struct GemmArgs {
   const f16 *res2;
   f16 *d;
   const char *zero;
-  int64_t lda, ldr1, ldr2, ldd, hw, bias2_rows;
+  int64_t lda, ldr1, ldr2, ldd, hw, bias2_rows, ldb2;
   int mode, cin, taps;
   int n_img, hin, win, hout, wout, stride, ups;
   int frames;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f16_kernel(const GemmArgs p) 
         if (p.bias2) {
           const int64_t m = (int64_t)tile_m * BM + ml;
           const int64_t brow = m < p.m ? m / p.bias2_rows : 0;
-          v += *(const f32x4 *)(p.bias2 + brow * p.n + n);
+          v += *(const f32x4 *)(p.bias2 + brow * p.ldb2 + n);
         }
         v *= p.oscale;
         f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
@@ -337,6 +337,7 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   a.oscale = d->oscale; a.r1scale = d->r1scale; a.r2scale = d->r2scale;
   a.geglu = d->geglu; a.n_store = d->n_store;
   a.bias2_rows = d->bias2_rows > 0 ? d->bias2_rows : d->m;
+  a.ldb2 = d->ldb2 > 0 ? d->ldb2 : d->n;
   if (d->res1) SP_REQUIRE(d->ldr1 % 8 == 0, "sp_gemm_f16: ldr1 must be a multiple of 8");
   if (d->res2) SP_REQUIRE(d->ldr2 % 8 == 0, "sp_gemm_f16: ldr2 must be a multiple of 8");
   if (d->mode == SP_A_CONV3X3) {

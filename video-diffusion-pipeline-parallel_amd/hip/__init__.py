@@ -24,6 +24,7 @@ class GemmDesc(ctypes.Structure):
         ("frames", ctypes.c_int), ("hw", ctypes.c_int64),
         ("w", ctypes.c_void_p), ("m", ctypes.c_int), ("n", ctypes.c_int),
         ("bias", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("bias2_rows", ctypes.c_int64),
+        ("ldb2", ctypes.c_int64),
         ("res1", ctypes.c_void_p), ("ldr1", ctypes.c_int64), ("r1scale", ctypes.c_float),
         ("res2", ctypes.c_void_p), ("ldr2", ctypes.c_int64), ("r2scale", ctypes.c_float),
         ("oscale", ctypes.c_float), ("geglu", ctypes.c_int), ("n_store", ctypes.c_int),

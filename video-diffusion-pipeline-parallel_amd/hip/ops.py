@@ -46,7 +46,7 @@ def _f16(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=None, bias=None,
-         bias2=None, bias2_rows=0, res1=None, r1scale=1.0, res2=None, r2scale=1.0, oscale=1.0,
+         bias2=None, bias2_rows=0, ldb2=0, res1=None, r1scale=1.0, res2=None, r2scale=1.0, oscale=1.0,
          geglu=False, n_store=0, ldd=None, ldr1=None, ldr2=None):
     """``out[m][:] = epilogue(sum_taps A_tap @ W^T)``; see ``sp_gemm_desc`` in include/svdpipe.h."""
     d = GemmDesc()
@@ -56,7 +56,7 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
     if mode == A_TEMPORAL3:
         d.frames, d.hw = temporal
     d.w, d.m, d.n = _f16(w, "w").data_ptr(), m, n
-    d.bias, d.bias2, d.bias2_rows = _ptr(bias), _ptr(bias2), bias2_rows
+    d.bias, d.bias2, d.bias2_rows, d.ldb2 = _ptr(bias), _ptr(bias2), bias2_rows, ldb2
     nout = n // 2 if geglu else n
     d.res1, d.ldr1, d.r1scale = _ptr(res1), int(ldr1 if ldr1 is not None else nout), r1scale
     d.res2, d.ldr2, d.r2scale = _ptr(res2), int(ldr2 if ldr2 is not None else nout), r2scale
