@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Headline benchmark: steady-state videos/s of SVD 14-frame x 25-step denoising on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" of this benchmark is ONE VIDEO: a synthetic 14-frame 576x1024 latent (1,4,14,72,128) fp16
+pushed through all 25 diffusion steps of the SVD UNet (random weights of the exact architecture, dummy
+conditioning like the reference's ``set_dummy_conditioning``, no CFG = the reference benchmark default,
+``/root/reference/src/modes/benchmark.py:60``).  With N > 1 the 25 steps are split into contiguous
+stages over the ranks (balanced split, e.g. [4,3,3,3,3,3,3,3]) and latents move stage-to-stage by RCCL
+send/recv on a side stream (``vdpp_amd.pipeline.PipelineStage``).
+
+The JSON line carries: metric/value (K videos / max-over-ranks wall time of the barrier-bracketed timed
+region), ``roofline`` for the dominant kernel (the implicit-GEMM MFMA kernel: algorithmic FLOPs of its
+launches in one UNet forward / their summed HIP-event durations, vs the 2.5 PFLOP/s dense fp16 peak),
+``step_roofline`` (whole UNet forward), ``cpu_baseline`` (the oracle's fp32 UNet restatement timed on the
+host cores on a bounded sample, rank 0 at N=1 only) and ``cpu_simulator`` (the reference's CPU
+simulator-mode path = DummyUNet step pipeline, as re-implemented here + the C oracle).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import vdpp_amd  # noqa: E402,F401
+from vdpp_amd.distributed import finalize_distributed, init_distributed, resolve_backend  # noqa: E402
+from vdpp_amd.pipeline import LatentSpec, PipelineConfig, PipelineStage, stage_sizes  # noqa: E402
+
+PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+FRAMES, LAT_H, LAT_W, TOTAL_STEPS = 14, 72, 128, 25
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="videos in the timed region")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up videos")
+    ap.add_argument("--frames", type=int, default=FRAMES)
+    ap.add_argument("--height", type=int, default=LAT_H)
+    ap.add_argument("--width", type=int, default=LAT_W)
+    ap.add_argument("--total-steps", type=int, default=TOTAL_STEPS)
+    ap.add_argument("--guidance-scale", type=float, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--seed", type=int, default=42)
+    return ap.parse_args()
+
+
+def cpu_baseline(frames_full, h, w, total_steps):
+    """Oracle fp32 UNet (plain PyTorch CPU) on a bounded sample: one forward at 2 frames; scaled by the
+    algorithmic FLOP ratio to 14 frames x total_steps."""
+    from oracle.svd_unet_ref import SVDUNetConfig, SVDUNetRef, unet_flops
+
+    cores = os.cpu_count() or 1
+    threads = min(cores, 16)
+    torch.set_num_threads(threads)
+    cfg = SVDUNetConfig.svd()
+    with torch.device("meta"):
+        ref = SVDUNetRef(cfg)
+    ref = ref.to_empty(device="cpu").eval()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.fill_(0.01)
+    sample_frames = 2
+    x = torch.randn(1, sample_frames, 8, h, w)
+    ctx = torch.randn(1, 1, cfg.cross_attention_dim)
+    ids = torch.tensor([[5.0, 127.0, 0.02]])
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref(x, 1.0, ctx, ids)
+    dt = time.perf_counter() - t0
+    scale = unet_flops(cfg, frames_full, h, w)["total"] / unet_flops(cfg, sample_frames, h, w)["total"]
+    videos_per_s = 1.0 / (dt * scale * total_steps)
+    del ref
+    return {"value": videos_per_s, "unit": "videos/s", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32 UNet (torch CPU), 1 forward at {sample_frames} of {frames_full} frames "
+                      f"{h}x{w} in {dt:.1f}s, scaled by FLOP ratio {scale:.2f} x {total_steps} steps"}
+
+
+def cpu_simulator():
+    """The reference's CPU simulator-mode path (DummyUNet(8,16), latent (1,8,8,32,32) fp32, 8 steps)."""
+    import numpy as np
+
+    from oracle import dummy_ref
+    from vdpp_amd.models import DummyUNet
+    from vdpp_amd.pipeline import run_single_latent
+
+    torch.manual_seed(1234)
+    model = DummyUNet(8, 16)
+    x = torch.randn(1, 8, 8, 32, 32)
+    spec = LatentSpec(shape=x.shape, dtype=torch.float32, device=torch.device("cpu"))
+    ts = list(reversed(range(8)))
+    import logging
+    quiet = logging.getLogger("bench.quiet"); quiet.setLevel(logging.ERROR)
+    with torch.no_grad():
+        run_single_latent(model, total_steps=8, timesteps=ts, world_size=1, rank=0, latent_spec=spec,
+                          input_latent=x, logger=quiet)
+        t0 = time.perf_counter(); reps = 5
+        for _ in range(reps):
+            run_single_latent(model, total_steps=8, timesteps=ts, world_size=1, rank=0, latent_spec=spec,
+                              input_latent=x, logger=quiet)
+        t_torch = (time.perf_counter() - t0) / reps
+    params = {k: v.numpy() for k, v in model.state_dict().items()}
+    dummy_ref.run_steps(x.numpy(), ts, 0, 8, params)
+    t0 = time.perf_counter()
+    dummy_ref.run_steps(x.numpy(), ts, 0, 8, params)
+    t_c = time.perf_counter() - t0
+    return {"workload": "DummyUNet(8,16) (1,8,8,32,32) fp32, 8 steps, world_size 1",
+            "torch_cpu_samples_per_s": 1.0 / t_torch, "torch_threads": torch.get_num_threads(),
+            "c_oracle_samples_per_s": 1.0 / t_c, "c_oracle_threads": 1}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    n = world
+    steps = args.steps if args.steps is not None else (4 if n == 1 else 4 * n)
+    warmup = args.warmup if args.warmup is not None else (1 if n == 1 else n)
+
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    if n > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        init_distributed(backend=resolve_backend(None, simulator=False), rank=rank, world_size=n)
+
+    from oracle.svd_unet_ref import SVDUNetConfig, unet_flops
+    from vdpp_amd.hip import ops
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+
+    T = args.total_steps
+    model = StableVideoUNet.from_random_init(StableVideoUNet._default_timestep_schedule(T), seed=0, device=device)
+    torch.manual_seed(args.seed)  # same dummy conditioning on every rank
+    model.set_dummy_conditioning(1, args.frames, args.height, args.width, device,
+                                 guidance_scale=args.guidance_scale)
+    passes = 2 if (args.guidance_scale or 0) > 1.0 else 1
+    shape = torch.Size((1, 4, args.frames, args.height, args.width))
+    spec = LatentSpec(shape=shape, dtype=torch.float16, device=device)
+    import logging
+    quiet = logging.getLogger("bench.quiet"); quiet.setLevel(logging.ERROR)
+    stage = PipelineStage(model, PipelineConfig(total_steps=T, world_size=n, rank=rank, timesteps=list(range(T)),
+                                                latent_spec=spec, balanced=True), logger=quiet)
+    gen = torch.Generator(device=device)
+
+    def supplier(i):
+        gen.manual_seed(args.seed + i)
+        return torch.randn(shape, generator=gen, device=device, dtype=torch.float16) * model.init_noise_sigma
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if n > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    with torch.no_grad():
+        if warmup > 0:
+            stage.run_many(warmup, input_supplier=supplier if rank == 0 else None)
+            stage.drain()
+        fence()
+        done_events = []
+        t0 = time.perf_counter()
+        start_ev = torch.cuda.Event(enable_timing=True); start_ev.record()
+        stage._more_samples_expected = True
+        for i in range(steps):
+            stage._more_samples_expected = i + 1 < steps
+            stage._process_single_latent(supplier(warmup + i) if rank == 0 else None, sample_idx=i)
+            if rank == n - 1:
+                ev = torch.cuda.Event(enable_timing=True); ev.record(); done_events.append(ev)
+        stage.drain()
+        fence()
+        elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if n > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    # steady-state figure in the reference's definition (benchmark.py:254-267): successive completion
+    # times on the last rank, first N-1 samples of the timed region (pipe fill) dropped
+    steady = None
+    fill = None
+    if rank == n - 1:
+        times = [start_ev.elapsed_time(e) / 1e3 for e in done_events]
+        fill = times[0]
+        drop = min(n - 1, len(times) - 1) if n > 1 else 0
+        if len(times) - drop >= 2:
+            steady = (len(times) - drop - 1) / (times[-1] - times[drop])
+        elif n == 1:
+            steady = len(times) / times[-1]
+    info = torch.tensor([steady or 0.0, fill or 0.0], dtype=torch.float64, device=device)
+    if n > 1:
+        dist.broadcast(info, src=n - 1)
+    steady, fill = float(info[0]), float(info[1])
+
+    out = None
+    if rank == 0:
+        value = steps / elapsed
+        flops_all = unet_flops(SVDUNetConfig.svd(), args.frames, args.height, args.width)
+        flops_exec = unet_flops(SVDUNetConfig.svd(), args.frames, args.height, args.width,
+                                count_cross_attn_qo=False)["total"]
+        out = {
+            "metric": "steady-state videos/sec (whole node), SVD 14f x 25step",
+            "value": value, "unit": "videos/s", "n_gpus": n, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"SVD img2vid UNet (1.52B params, random init), latent (1,4,{args.frames},"
+                                   f"{args.height},{args.width}) fp16, {T} steps, {passes} UNet pass/step "
+                                   f"(guidance_scale={args.guidance_scale}), 1 video per pipeline slot",
+                       "stage_steps": stage_sizes(T, n, balanced=True),
+                       "parallelism": f"step-pipeline pp{n}" if n > 1 else "single GPU (no pipeline split)"},
+            "steady_state_videos_per_s_last_rank": steady, "first_video_latency_s": fill,
+            "unet_forward_tflop_algorithmic": flops_all["total"] / 1e12,
+            "unet_forward_tflop_executed": flops_exec / 1e12,
+        }
+        ms_forward = 1e3 * elapsed / steps / (T * passes) if n == 1 else None
+        if ms_forward:
+            out["ms_per_unet_forward"] = ms_forward
+            out["step_roofline"] = {"bound": "mfma", "achieved": flops_exec / 1e12 / (ms_forward / 1e3),
+                                    "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": flops_exec / 1e12 / (ms_forward / 1e3) / PEAK_FP16_TFLOPS}
+
+    # ---- per-kernel roofline of the dominant kernel, measured live with events on the launch stream
+    if rank == 0 and not args.no_roofline:
+        with torch.no_grad():
+            ops.PROFILE = []
+            lat = supplier(0)
+            model(lat, 0)
+            torch.cuda.synchronize(device)
+            prof, ops.PROFILE = ops.PROFILE, None
+        by = {}
+        for kind, fl, e0, e1 in prof:
+            acc = by.setdefault(kind, [0.0, 0.0, 0])
+            acc[0] += fl; acc[1] += e0.elapsed_time(e1) / 1e3; acc[2] += 1
+        gf, gt, gn = by["gemm"]
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_f16_kernel (implicit-GEMM conv/linear)",
+                           "achieved": gf / gt / 1e12, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": gf / gt / 1e12 / PEAK_FP16_TFLOPS, "traffic": None,
+                           "launches_per_forward": gn, "avg_launch_us": 1e6 * gt / gn,
+                           "flop_per_launch_avg": gf / gn}
+        if "attn_spatial" in by:
+            af, at, an = by["attn_spatial"]
+            out["roofline_attention"] = {"bound": "mfma", "kernel": "attn_spatial_kernel",
+                                         "achieved": af / at / 1e12, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": af / at / 1e12 / PEAK_FP16_TFLOPS, "launches_per_forward": an,
+                                         "avg_launch_us": 1e6 * at / an}
+    if rank == 0 and n == 1 and not args.no_cpu_baseline:
+        del model, stage
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(args.frames, args.height, args.width, T)
+        out["cpu_simulator"] = cpu_simulator()
+    if rank == 0:
+        print(json.dumps(out))
+    if n > 1:
+        finalize_distributed()
+
+
+if __name__ == "__main__":
+    main()

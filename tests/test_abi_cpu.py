@@ -1,0 +1,60 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/svdpipe.h declares; argument
+validation rejects bad descriptors before anything is launched (no compute calls here)."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+from vdpp_amd import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported():
+    header = open(os.path.join(ROOT, "include", "svdpipe.h")).read()
+    declared = set(re.findall(r"\b(sp_[a-z0-9_]+)\s*\(", header))
+    declared -= {"sp_gemm_desc"}
+    assert declared, "no declarations parsed"
+    lib = hip.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in svdpipe.h but not exported"
+    assert declared == set(hip.SIGNATURES), "binding table and header disagree"
+    assert lib.sp_version() >= 100
+
+
+def test_gemm_desc_layout_matches_header():
+    # field order of the ctypes mirror == field order in the header
+    header = open(os.path.join(ROOT, "include", "svdpipe.h")).read()
+    body = header[header.index("typedef struct sp_gemm_desc {"):header.index("} sp_gemm_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for stmt in body.split("{", 1)[1].split(";"):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        parts = stmt.split(",")
+        first = re.sub(r"^(const\s+)?(void|float|int64_t|int)\s*\**\s*", "", parts[0].strip())
+        names.append(first.strip(" *"))
+        names.extend(p.strip(" *") for p in parts[1:])
+    assert names == [f[0] for f in hip.GemmDesc._fields_]
+
+
+def test_rejects_bad_arguments_without_launching():
+    lib = hip.load()
+    d = hip.GemmDesc()
+    assert lib.sp_gemm_f16(ctypes.byref(d), None) == -1
+    assert b"null" in lib.sp_last_error()
+    assert lib.sp_groupnorm_f16(None, None, None, None, 1, 1, 8, 32, 1e-5, 0, None, 0, None) == -1
+    assert lib.sp_layernorm_f16(None, None, 0, None, None, None, None, 1, 8, 1e-5, None) == -1
+    assert lib.sp_attn_spatial_f16(None, None, None, None, 64, 64, 64, 64, 1, 1, 1, 0.125, None, None) == -1
+    assert lib.sp_dummy_unet_f32(*([None] * 9), 1e-5, 1, 0.5, 1, 8, 16, 1, 1, 1, None) == -1
+    assert lib.sp_groupnorm_ws_bytes(14, 9216, 320, 32) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        hip.load()

@@ -1,0 +1,82 @@
+"""The oracle itself is pinned here: C restatement vs the reference-minted vectors, the step restatement vs
+the reference's own StableVideoUNet.forward outputs, the schedule vs the values the reference documents, and the
+product's host-side schedule vs the oracle's."""
+
+import math
+import os
+
+import numpy as np
+import torch
+
+from oracle import dummy_ref, euler_sched
+from oracle.svd_step_ref import svd_step
+from tests.golden.make_golden import _stub_unet
+
+
+def test_c_oracle_matches_reference_vectors(golden_dir):
+    for name in ("dummy_c8h16.npz", "dummy_c4h64.npz"):
+        z = np.load(os.path.join(golden_dir, name))
+        params = {k[6:]: z[k] for k in z.files if k.startswith("param.")}
+        ts = z["timesteps"].tolist()
+        out = dummy_ref.run_steps(z["input"], ts, 0, len(ts), params)
+        rel = np.linalg.norm(out.astype(np.float64) - z["final"]) / np.linalg.norm(z["final"])
+        assert rel < 2e-5, f"{name}: C oracle vs reference rel={rel:.2e}"   # fp32 reassociation only
+        # two stages (what world_size=2 does) == one pass; stage boundary matches the reference's hand-off
+        half = dummy_ref.run_steps(z["input"], ts, 0, len(ts) // 2, params)
+        relm = np.linalg.norm(half.astype(np.float64) - z["midpoint"]) / np.linalg.norm(z["midpoint"])
+        assert relm < 2e-5
+        both = dummy_ref.run_steps(half, ts, len(ts) // 2, len(ts), params)
+        assert both.tobytes() == out.tobytes()
+
+
+def test_step_oracle_matches_reference_forward(golden_dir):
+    z = np.load(os.path.join(golden_dir, "svd_step.npz"))
+    sig, ts = torch.from_numpy(z["sigmas"]), torch.from_numpy(z["scheduler_timesteps"])
+    emb, img = torch.from_numpy(z["image_embeddings"]), torch.from_numpy(z["image_latents"])
+    for dt_name, dt in (("fp32", torch.float32), ("fp16", torch.float16)):
+        ids = torch.from_numpy(z[f"added_time_ids.{dt_name}"]).to(dt)
+        for gs_name, gs in (("nocfg", None), ("cfg3", 3.0)):
+            for step in (0, 12, 24):
+                x = torch.from_numpy(z[f"in.{dt_name}.{gs_name}.{step}"]).to(dt)
+                got = svd_step(_stub_unet, x, step, sigmas=sig, timesteps=ts, image_embeddings=emb.to(dt),
+                               image_latents=img.to(dt), added_time_ids=ids, guidance_scale=gs, dtype=dt)
+                want = z[f"out.{dt_name}.{gs_name}.{step}"]
+                assert np.array_equal(got.float().numpy(), want), f"{dt_name} {gs_name} step {step}"
+
+
+def test_schedule_matches_documented_values(golden_dir):
+    s = euler_sched.karras_sigmas(25)
+    assert s.shape == (26,) and s[-1] == 0.0
+    assert abs(float(s[0]) - 700.0) < 1e-3                     # EXPERIMENT_RESULTS.md:237-251
+    assert abs(euler_sched.init_noise_sigma(s) - math.sqrt(700.0 ** 2 + 1)) < 1e-3
+    assert abs(float(s[1]) - 545.729) < 1e-2 and abs(float(s[24]) - 0.002) < 1e-6
+    t = euler_sched.continuous_timesteps(s)
+    assert abs(float(t[0]) - 1.63777) < 1e-4 and abs(float(t[-1]) + 1.55365) < 1e-4
+    assert np.all(np.diff(s) < 0)
+    assert euler_sched.default_timestep_schedule(25)[:3] == [999, 959, 919]
+    assert len(euler_sched.default_timestep_schedule(30)) == 30
+    z = np.load(os.path.join(golden_dir, "svd_step.npz"))      # table used when the fixture was minted
+    assert np.array_equal(z["sigmas"], s)
+
+
+def test_product_schedule_equals_oracle():
+    from vdpp_amd.models import euler_schedule
+    for n in (25, 30, 8):
+        mine = euler_schedule.karras_sigma_table(n).numpy()
+        ref = euler_sched.karras_sigmas(n)
+        assert np.allclose(mine, ref, rtol=1e-6, atol=0)
+        assert np.allclose(euler_schedule.continuous_timesteps(torch.from_numpy(mine)).numpy(),
+                           euler_sched.continuous_timesteps(ref), rtol=1e-6, atol=1e-7)
+
+
+def test_oracle_unet_inventory_matches_product_spec():
+    from oracle.svd_unet_ref import SVDUNetConfig, SVDUNetRef, unet_flops
+    from vdpp_amd.models.unet_spec import UNetConfig, param_count, param_inventory
+    with torch.device("meta"):
+        big = SVDUNetRef(SVDUNetConfig.svd())
+    assert {n: tuple(s) for n, s, _ in param_inventory(UNetConfig.svd())} == \
+        {n: tuple(p.shape) for n, p in big.state_dict().items()}
+    assert param_count(UNetConfig.svd()) == 1_524_623_082
+    f = unet_flops(SVDUNetConfig.svd(), 14, 72, 128)
+    assert abs(f["total"] / 1e12 - 44.69) < 0.01
+    assert abs(unet_flops(SVDUNetConfig.svd(), 25, 72, 128)["total"] / 1e12 - 79.83) < 0.01

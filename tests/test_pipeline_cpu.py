@@ -1,0 +1,162 @@
+"""CPU tests of the launcher / executor API and of the simulator path against the vectors minted from the
+reference (tests/golden/*.npz): DummyUNet pipeline over Gloo with world_size 1, 2 (and 4) must reproduce the
+reference's final latent BIT-EXACTLY (same torch CPU ops, same order)."""
+
+import logging
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from vdpp_amd.distributed import finalize_distributed, init_distributed, resolve_backend
+from vdpp_amd.models import DummyUNet
+from vdpp_amd.pipeline import LatentSpec, PipelineConfig, PipelineStage, run_pipeline_latents, run_single_latent
+
+
+def _load(golden_dir, name, c, hid):
+    z = np.load(os.path.join(golden_dir, name))
+    model = DummyUNet(c, hid)
+    model.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")})
+    return z, model.eval()
+
+
+def test_dummy_unet_matches_reference_per_step(golden_dir):
+    z, model = _load(golden_dir, "dummy_c4h64.npz", 4, 64)
+    lat = torch.from_numpy(z["input"])
+    with torch.no_grad():
+        for i, s in enumerate(z["timesteps"].tolist()):
+            lat = model(lat, s)
+            assert lat.numpy().tobytes() == z["per_step"][i].tobytes(), f"step {s} differs from the reference"
+
+
+def test_dummy_unet_shapes_like_reference_tests():
+    # mirrors what /root/reference/tests/test_dummy_unet.py checks (shape preservation, step accepted)
+    for c, shape in ((8, (1, 8, 8, 32, 32)), (4, (2, 4, 8, 32, 32)), (4, (4, 4, 8, 16, 16)), (8, (1, 8, 8, 64, 64))):
+        m = DummyUNet(channels=c)
+        for step in (0, 10, 27):
+            assert m(torch.randn(shape), step=step).shape == torch.Size(shape)
+    assert sum(p.numel() for p in DummyUNet(8, 16).parameters()) == 6952
+
+
+def _worker(rank, ws, golden_dir, name, c, hid, init_file, out_file, many):
+    torch.set_num_threads(2)
+    z, model = _load(golden_dir, name, c, hid)
+    init_distributed(backend=resolve_backend(None, simulator=True), rank=rank, world_size=ws,
+                     init_method=f"file://{init_file}")
+    x = torch.from_numpy(z["input"])
+    ts = z["timesteps"].tolist()
+    spec = LatentSpec(shape=x.shape, dtype=torch.float32, device=torch.device("cpu"))
+    quiet = logging.getLogger("quiet"); quiet.setLevel(logging.ERROR)
+    with torch.no_grad():
+        if many:
+            outs = run_pipeline_latents(model, total_steps=len(ts), timesteps=ts, world_size=ws, rank=rank,
+                                        latent_spec=spec, num_samples=3,
+                                        input_supplier=(lambda i: x * (1.0 if i != 1 else 0.5)) if rank == 0 else None,
+                                        logger=quiet)
+            if rank == ws - 1:
+                torch.save(outs, out_file)
+            else:
+                assert outs is None
+        else:
+            out = run_single_latent(model, total_steps=len(ts), timesteps=ts, world_size=ws, rank=rank,
+                                    latent_spec=spec, input_latent=x if rank == 0 else None, logger=quiet)
+            if rank == ws - 1:
+                torch.save(out, out_file)
+            else:
+                assert out is None
+    finalize_distributed()
+
+
+@pytest.mark.parametrize("name,c,hid,ws", [("dummy_c8h16.npz", 8, 16, 2), ("dummy_c4h64.npz", 4, 64, 2),
+                                           ("dummy_c4h64.npz", 4, 64, 4)])
+def test_gloo_pipeline_reproduces_reference_bit_exact(golden_dir, name, c, hid, ws):
+    with tempfile.TemporaryDirectory() as td:
+        out_file = os.path.join(td, "out.pt")
+        mp.spawn(_worker, args=(ws, golden_dir, name, c, hid, os.path.join(td, "init"), out_file, False),
+                 nprocs=ws, join=True)
+        got = torch.load(out_file).numpy()
+    want = np.load(os.path.join(golden_dir, name))["final"]
+    assert got.tobytes() == want.tobytes()
+
+
+def test_gloo_run_many_world2(golden_dir):
+    with tempfile.TemporaryDirectory() as td:
+        out_file = os.path.join(td, "out.pt")
+        mp.spawn(_worker, args=(2, golden_dir, "dummy_c4h64.npz", 4, 64, os.path.join(td, "init"), out_file, True),
+                 nprocs=2, join=True)
+        outs = torch.load(out_file)
+    want = np.load(os.path.join(golden_dir, "dummy_c4h64.npz"))["final"]
+    assert len(outs) == 3
+    assert outs[0].numpy().tobytes() == want.tobytes() and outs[2].numpy().tobytes() == want.tobytes()
+    assert not np.array_equal(outs[1].numpy(), want)
+
+
+def test_single_rank_matches_golden_and_passes_timestep_value(golden_dir):
+    z, model = _load(golden_dir, "dummy_c8h16.npz", 8, 16)
+    x = torch.from_numpy(z["input"])
+    ts = z["timesteps"].tolist()
+    spec = LatentSpec(shape=x.shape, dtype=torch.float32, device=torch.device("cpu"))
+    seen = []
+
+    def spy(latent, step):
+        seen.append(step)
+        return model(latent, step)
+
+    with torch.no_grad():
+        out = run_single_latent(spy, total_steps=8, timesteps=ts, world_size=1, rank=0, latent_spec=spec, input_latent=x)
+    assert seen == ts == [7, 6, 5, 4, 3, 2, 1, 0]          # the timestep VALUE is passed (ref pipeline.py:95)
+    assert out.numpy().tobytes() == z["final"].tobytes()
+    assert abs(float(out.norm()) - float(z["per_step_norm"][-1])) < 1e-2
+
+
+def test_executor_argument_errors():
+    spec = LatentSpec(shape=torch.Size((1, 2, 1, 2, 2)), dtype=torch.float32, device=torch.device("cpu"))
+    with pytest.raises(ValueError):
+        PipelineConfig(total_steps=4, world_size=1, rank=0, timesteps=[3, 2, 1], latent_spec=spec)
+    cfg = PipelineConfig(total_steps=4, world_size=1, rank=0, timesteps=[3, 2, 1, 0], latent_spec=spec)
+    stage = PipelineStage(lambda l, s: l, cfg)
+    with pytest.raises(ValueError):
+        stage.run(None)                                     # rank 0 needs a latent
+    with pytest.raises(ValueError):
+        stage.run_many(0, input_supplier=lambda i: torch.zeros(spec.shape))
+    with pytest.raises(ValueError):
+        stage.run_many(2)                                   # rank 0 needs a supplier
+    with pytest.raises(ValueError):
+        PipelineStage(lambda l, s: l, PipelineConfig(total_steps=5, world_size=2, rank=0,
+                                                     timesteps=list(range(5)), latent_spec=spec))
+    mid = PipelineStage(lambda l, s: l, PipelineConfig(total_steps=4, world_size=2, rank=1,
+                                                       timesteps=[3, 2, 1, 0], latent_spec=spec))
+    with pytest.raises(ValueError):
+        mid.run(torch.zeros(spec.shape))                    # non-zero ranks must pass None
+    bal = PipelineStage(lambda l, s: l, PipelineConfig(total_steps=5, world_size=2, rank=1, timesteps=list(range(5)),
+                                                       latent_spec=spec, balanced=True))
+    assert (bal.step_range.start, bal.step_range.end) == (3, 5)
+    assert spec.empty().shape == spec.shape
+
+
+def test_backend_resolution(monkeypatch):
+    monkeypatch.delenv("PIPELINE_BACKEND", raising=False)
+    assert resolve_backend(None, simulator=True) == "gloo"
+    assert resolve_backend(None, simulator=False) == "nccl"
+    assert resolve_backend("GLOO") == "gloo"
+    monkeypatch.setenv("PIPELINE_BACKEND", "gloo")
+    assert resolve_backend(None, simulator=False) == "gloo"
+    assert resolve_backend("nccl", simulator=True) == "nccl"    # argument beats env
+    monkeypatch.setenv("PIPELINE_BACKEND", "mpi")
+    with pytest.raises(ValueError):
+        resolve_backend(None)
+    with pytest.raises(ValueError):
+        resolve_backend("ucc")
+
+
+def test_init_is_idempotent_and_finalize_safe():
+    finalize_distributed()                                   # nothing initialised: no-op
+    with tempfile.TemporaryDirectory() as td:
+        init_distributed(backend="gloo", rank=0, world_size=1, init_method=f"file://{td}/i")
+        init_distributed(backend="gloo", rank=0, world_size=1, init_method=f"file://{td}/j")  # second call ignored
+        assert torch.distributed.is_initialized()
+        finalize_distributed()
+        assert not torch.distributed.is_initialized()

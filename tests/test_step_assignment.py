@@ -1,0 +1,68 @@
+"""Step-assignment known-answer tests.  Same KAT set the reference pins
+(/root/reference/tests/test_step_assignment.py: 28 steps over 1/2/4/7 ranks, 29/7 rejected, StepRange
+count/iteration/validation) expressed as tables, plus the balanced-split extension."""
+
+import pytest
+
+from vdpp_amd.pipeline.step_assignment import StepRange, assign_steps, assign_steps_balanced, stage_sizes
+
+KAT_28 = {
+    1: [(0, 28)],
+    2: [(0, 14), (14, 28)],
+    4: [(0, 7), (7, 14), (14, 21), (21, 28)],
+    7: [(4 * r, 4 * r + 4) for r in range(7)],
+}
+
+
+@pytest.mark.parametrize("world", sorted(KAT_28))
+def test_uniform_split_known_answers(world):
+    got = [assign_steps(28, world, r) for r in range(world)]
+    assert [(s.start, s.end) for s in got] == KAT_28[world]
+    assert all(s.count == 28 // world for s in got)
+
+
+@pytest.mark.parametrize("total,world", [(28, 7), (8, 2), (30, 5), (105, 7)])
+def test_partition_is_exact(total, world):
+    seen = []
+    for r in range(world):
+        seen.extend(assign_steps(total, world, r))
+    assert seen == list(range(total))
+
+
+@pytest.mark.parametrize("kwargs", [
+    dict(total_steps=0, world_size=1, rank=0), dict(total_steps=-1, world_size=1, rank=0),
+    dict(total_steps=28, world_size=0, rank=0), dict(total_steps=28, world_size=4, rank=4),
+    dict(total_steps=28, world_size=4, rank=-1), dict(total_steps=29, world_size=7, rank=0),
+    dict(total_steps=25, world_size=8, rank=0),
+])
+def test_invalid_arguments_raise(kwargs):
+    with pytest.raises(ValueError):
+        assign_steps(**kwargs)
+
+
+def test_step_range_behaviour():
+    sr = StepRange(start=5, end=10)
+    assert sr.count == 5 and list(sr) == [5, 6, 7, 8, 9]
+    assert StepRange(0, 7).count == 7 and StepRange(3, 3).count == 0
+    for bad in ((-1, 5), (10, 5), (0, -2)):
+        with pytest.raises(ValueError):
+            StepRange(*bad)
+    with pytest.raises(Exception):
+        sr.start = 1  # frozen
+
+
+def test_balanced_split_extension():
+    assert stage_sizes(25, 8, balanced=True) == [4, 3, 3, 3, 3, 3, 3, 3]
+    assert stage_sizes(25, 4, balanced=True) == [7, 6, 6, 6]
+    assert stage_sizes(25, 2, balanced=True) == [13, 12]
+    assert stage_sizes(30, 8, balanced=True) == [4, 4, 4, 4, 4, 4, 3, 3]
+    assert stage_sizes(28, 7, balanced=True) == stage_sizes(28, 7) == [4] * 7
+    for total, world in [(25, 8), (30, 8), (7, 7), (9, 2)]:
+        seen = []
+        for r in range(world):
+            seen.extend(assign_steps_balanced(total, world, r))
+        assert seen == list(range(total))
+    with pytest.raises(ValueError):
+        assign_steps_balanced(3, 4, 0)
+    with pytest.raises(ValueError):
+        assign_steps_balanced(25, 8, 8)

@@ -332,6 +332,7 @@ extern "C" int sp_attn_spatial_f16(const void *q, const void *k, const void *v, 
   SP_REQUIRE(batch > 0 && seq > 0 && heads > 0, "sp_attn_spatial_f16: batch/seq/heads must be positive");
   SP_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "sp_attn_spatial_f16: strides must be multiples of 8");
   SP_REQUIRE((int64_t)batch * heads <= 65535, "sp_attn_spatial_f16: batch*heads too large");
+  SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(attn_spatial_kernel, dim3((seq + 127) / 128, batch * heads), dim3(256), 0,
                      (hipStream_t)stream, (const f16 *)q, (const f16 *)k, (const f16 *)v, (f16 *)o, ldq, ldk,
                      ldv, ldo, seq, heads, scale * 1.4426950408889634f, (const char *)zero_page);
@@ -350,6 +351,7 @@ extern "C" int sp_attn_temporal_f16(const void *q, const void *k, const void *v,
   const unsigned grid = (unsigned)((nprob + 3) / 4);
   const float sl = scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
+  SP_CLEAR_STALE_ERROR();
   if (frames <= 16)
     hipLaunchKernelGGL(attn_temporal_kernel<1>, dim3(grid), dim3(256), 0, s, (const f16 *)q, (const f16 *)k,
                        (const f16 *)v, (f16 *)o, ldq, ldk, ldv, ldo, frames, hw, heads, nprob, sl,

@@ -25,6 +25,10 @@ void sp_set_error(const char *fmt, ...);
     }                                         \
   } while (0)
 
+// hipGetLastError() reports the last error of ANY earlier runtime call on this thread (PyTorch,
+// profilers, ...); reading it here resets it so SP_CHECK_LAUNCH only sees this launch's status.
+#define SP_CLEAR_STALE_ERROR() ((void)hipGetLastError())
+
 #define SP_CHECK_LAUNCH(name)                                             \
   do {                                                                    \
     hipError_t e__ = hipGetLastError();                                   \

@@ -87,9 +87,11 @@ extern "C" int sp_dummy_unet_f32(const float *x, float *out, float *hidden, cons
   const int64_t total = (int64_t)b * frames * h * w;
   const unsigned grid = (unsigned)((total + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
+  SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(dummy_conv_kernel<false>, dim3(grid), dim3(256), 0, s, x, w1, b1, hidden, nullptr, nullptr,
                      nullptr, 0.f, 0, 0.f, b, c, hidden_c, frames, h, w);
   SP_CHECK_LAUNCH("sp_dummy_unet_f32(conv1)");
+  SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(dummy_conv_kernel<true>, dim3(grid), dim3(256), 0, s, hidden, w2, b2, out, x, ln_w, ln_b,
                      ln_eps, use_ln, gain, b, hidden_c, c, frames, h, w);
   SP_CHECK_LAUNCH("sp_dummy_unet_f32(conv2)");

@@ -134,6 +134,7 @@ extern "C" int sp_pack_input_f16(const void *latent, const void *image_latents, 
   SP_REQUIRE(b > 0 && frames > 0 && h > 0 && w > 0, "sp_pack_input_f16: dims must be positive");
   SP_REQUIRE(cpad >= 8 && cpad % 8 == 0, "sp_pack_input_f16: cpad=%d must be a multiple of 8, >= 8", cpad);
   const int64_t hw = (int64_t)h * w, total = (int64_t)b * frames * hw;
+  SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, (const f16 *)latent, (const f16 *)image_latents, (f16 *)out,
                      in_scale, frames, hw, cpad, total);
@@ -150,6 +151,7 @@ extern "C" int sp_euler_step_f16(const void *latent, const void *eps_cond, const
   SP_REQUIRE(sigma > 0.f, "sp_euler_step_f16: sigma must be positive");
   const int64_t hw = (int64_t)h * w, total = (int64_t)b * frames * hw;
   const float s2 = sigma * sigma + 1.0f;
+  SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(euler_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, (const f16 *)latent, (const f16 *)eps_cond,
                      (const f16 *)eps_uncond, ld_eps, guidance, (f16 *)out, -sigma / sqrtf(s2), 1.0f / s2,
@@ -163,6 +165,7 @@ extern "C" int sp_concat_channels_f16(const void *a, int ca, const void *b, int 
   SP_REQUIRE(a && b && out, "sp_concat_channels_f16: null pointer");
   SP_REQUIRE(ca > 0 && cb > 0 && ca % 8 == 0 && cb % 8 == 0, "sp_concat_channels_f16: channels must be multiples of 8");
   const int64_t total = rows * ((ca + cb) / 8);
+  SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(concat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const f16 *)a, ca / 8, (const f16 *)b, cb / 8, (f16 *)out, total);
   SP_CHECK_LAUNCH("sp_concat_channels_f16");
@@ -172,6 +175,7 @@ extern "C" int sp_concat_channels_f16(const void *a, int ca, const void *b, int 
 extern "C" int sp_add_rowvec_f16(const void *x, const float *vec, void *y, int64_t rows, int c, void *stream) {
   SP_REQUIRE(x && vec && y && rows > 0 && c % 8 == 0, "sp_add_rowvec_f16: bad arguments");
   const int64_t total = rows * (c / 8);
+  SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(add_rowvec_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, (const f16 *)x, vec, (f16 *)y, c / 8, total);
   SP_CHECK_LAUNCH("sp_add_rowvec_f16");
@@ -182,6 +186,7 @@ extern "C" int sp_gemv_f16(const void *x, int64_t ldx, const void *w, const floa
                            int64_t ldy, int rows, int n, int k, int silu_in, int silu_out, void *stream) {
   SP_REQUIRE(x && w && (y || y_f16), "sp_gemv_f16: null pointer");
   SP_REQUIRE(rows > 0 && n > 0 && k > 0 && k % 8 == 0 && ldx % 8 == 0, "sp_gemv_f16: bad shape rows=%d n=%d k=%d", rows, n, k);
+  SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(gemv_kernel, dim3((n + 3) / 4, rows), dim3(256), 0, (hipStream_t)stream, (const f16 *)x,
                      ldx, (const f16 *)w, b, y, (f16 *)y_f16, ldy, n, k, silu_in, silu_out);
   SP_CHECK_LAUNCH("sp_gemv_f16");
@@ -191,6 +196,7 @@ extern "C" int sp_gemv_f16(const void *x, int64_t ldx, const void *w, const floa
 extern "C" int sp_sinusoid_f16(const float *values, void *out, int count, int dim, void *stream) {
   SP_REQUIRE(values && out && count > 0 && dim > 0 && dim % 2 == 0, "sp_sinusoid_f16: bad arguments");
   const int total = count * (dim / 2);
+  SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(sinusoid_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, values,
                      (f16 *)out, count, dim);
   SP_CHECK_LAUNCH("sp_sinusoid_f16");

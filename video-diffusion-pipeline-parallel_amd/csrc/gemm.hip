@@ -310,6 +310,7 @@ int launch(const GemmArgs &a, hipStream_t s) {
                         (int)lds);
     attr_set = true;
   }
+  SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(gemm_f16_kernel<BN>, dim3(a.tiles_m * a.tiles_n), dim3(THREADS), lds, s, a);
   SP_CHECK_LAUNCH("sp_gemm_f16");
   return SP_OK;

@@ -1,12 +1,12 @@
 // GroupNorm(+SiLU) and LayerNorm for channels-last fp16 token matrices (HBM-bound kernels).
 //
-// GroupNorm: two launches.
+// GroupNorm: three launches.
 //   stats : grid (instances, splits); every thread owns one 8-channel octet (16-byte loads, rows
 //           strided by P), accumulates per-channel sum / sum-of-squares in fp32 registers, the block
 //           reduces them in LDS in a FIXED order (deterministic, no atomics) to per-group partials
 //           and writes [instance][split][group][2].
-//   apply : each block first folds the `splits` partials of its instance (fixed order, fp64 for the
-//           variance), then streams rows: y = x*scale[c] + shift[c], optional SiLU, 16-byte stores.
+//   final : one block per instance folds the partials (fixed order, fp64) into mean / rstd.
+//   apply : streams rows: y = x*scale[c] + shift[c], optional SiLU, 16-byte loads/stores.
 // The second read of x is served mostly by the 256 MiB Infinity Cache (tensors are <= 83 MB).
 #include "common.h"
 
@@ -56,37 +56,55 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
   }
 }
 
-__global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restrict__ part,
+// one block per instance: fold the per-split partials into mean / rstd (fixed order, fp64)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ part,
+                                                          float *__restrict__ stats, int64_t rows, int c,
+                                                          int groups, int splits, float eps) {
+  __shared__ double sh[256 * 2];
+  const int tid = threadIdx.x, inst = blockIdx.x;
+  const int slices = 256 / groups;
+  const int g = tid % groups, sl = tid / groups;
+  double a = 0.0, b = 0.0;
+  if (sl < slices) {
+    const float *src = part + ((int64_t)inst * splits * groups + g) * 2;
+    for (int sp = sl; sp < splits; sp += slices) {
+      a += src[(int64_t)sp * groups * 2];
+      b += src[(int64_t)sp * groups * 2 + 1];
+    }
+  }
+  sh[tid * 2] = a; sh[tid * 2 + 1] = b;
+  __syncthreads();
+  if (tid < groups) {
+    a = 0.0; b = 0.0;
+    for (int q = 0; q < slices; ++q) { a += sh[(q * groups + tid) * 2]; b += sh[(q * groups + tid) * 2 + 1]; }
+    const double cnt = (double)rows * (c / groups);
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean; if (var < 0.0) var = 0.0;
+    stats[((int64_t)inst * groups + tid) * 2] = (float)mean;
+    stats[((int64_t)inst * groups + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+__global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restrict__ stats,
                                 const float *__restrict__ gamma, const float *__restrict__ beta,
-                                f16 *__restrict__ y, int64_t rows, int c, int groups, int splits,
-                                float eps, int silu, int64_t rows_per_block) {
-  __shared__ float sh_mean[64], sh_rstd[64];
+                                f16 *__restrict__ y, int64_t rows, int c, int groups, int silu,
+                                int64_t rows_per_block) {
   const int oc = c >> 3;
   const int P = gn_rows_per_iter(oc);
   const int tid = threadIdx.x;
   const int inst = blockIdx.x;
-  if (tid < groups) {
-    double a = 0.0, b = 0.0;
-    const float *src = part + ((int64_t)inst * splits * groups + tid) * 2;
-    for (int sp = 0; sp < splits; ++sp) { a += src[(int64_t)sp * groups * 2]; b += src[(int64_t)sp * groups * 2 + 1]; }
-    const double cnt = (double)rows * (c / groups);
-    const double mean = a / cnt;
-    double var = b / cnt - mean * mean; if (var < 0.0) var = 0.0;
-    sh_mean[tid] = (float)mean;
-    sh_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-  __syncthreads();
   const int o = tid % oc, pr = tid / oc;
   if (pr >= P) return;
   const int cpg = c / groups;
+  const float *st = stats + (int64_t)inst * groups * 2;
   float sc[8], sf[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ch = o * 8 + e;
     const int g = ch / cpg;
     const float ga = gamma ? gamma[ch] : 1.f, be = beta ? beta[ch] : 0.f;
-    sc[e] = sh_rstd[g] * ga;
-    sf[e] = be - sh_mean[g] * sc[e];
+    sc[e] = st[g * 2 + 1] * ga;
+    sf[e] = be - st[g * 2] * sc[e];
   }
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
@@ -177,7 +195,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16 *__restrict__ x, cons
 
 extern "C" size_t sp_groupnorm_ws_bytes(int instances, int64_t rows, int c, int groups) {
   if (instances <= 0 || rows <= 0 || c <= 0 || groups <= 0) return 0;
-  return (size_t)instances * 512 * groups * 2 * sizeof(float);
+  return (size_t)instances * (512 + 1) * groups * 2 * sizeof(float);
 }
 
 extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *beta, void *y,
@@ -195,6 +213,7 @@ extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *
   const int splits = gn_splits(instances, rows, P);
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)P * c * 2 * sizeof(float);
+  SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(gn_stats_kernel, dim3(instances, splits), dim3(threads), lds, s, (const f16 *)x,
                      (float *)ws, rows, c, groups, splits);
   SP_CHECK_LAUNCH("sp_groupnorm_f16(stats)");
@@ -204,9 +223,13 @@ extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *
   if (blocks_y < 1) blocks_y = 1;
   const int64_t rpb = (rows + blocks_y - 1) / blocks_y;
   blocks_y = (rows + rpb - 1) / rpb;
+  SP_CLEAR_STALE_ERROR();
+  float *stats = (float *)ws + (size_t)instances * splits * groups * 2;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(instances), dim3(256), 0, s, (const float *)ws, stats, rows, c,
+                     groups, splits, eps);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(instances, (unsigned)blocks_y), dim3(threads), 0, s,
-                     (const f16 *)x, (const float *)ws, gamma, beta, (f16 *)y, rows, c, groups, splits,
-                     eps, fuse_silu, rpb);
+                     (const f16 *)x, (const float *)stats, gamma, beta, (f16 *)y, rows, c, groups, fuse_silu,
+                     rpb);
   SP_CHECK_LAUNCH("sp_groupnorm_f16(apply)");
   return SP_OK;
 }
@@ -221,6 +244,7 @@ extern "C" int sp_layernorm_f16(const void *x, const void *addvec, int64_t addve
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)((rows + 3) / 4);
   const int oc = c / 8;
+  SP_CLEAR_STALE_ERROR();
 #define LN_LAUNCH(NV)                                                                              \
   hipLaunchKernelGGL(ln_kernel<NV>, dim3(grid), dim3(256), 0, s, (const f16 *)x, (const f16 *)addvec, \
                      addvec_rows > 0 ? addvec_rows : 1, (f16 *)sum_out, gamma, beta, (f16 *)y, rows, c, eps)

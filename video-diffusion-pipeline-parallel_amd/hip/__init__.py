@@ -63,6 +63,8 @@ def load():
                 "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C csrc`). "
                 "There is no CPU/PyTorch fallback for the GPU path."
             )
+        import torch  # noqa: F401  load PyTorch's HIP runtime first so both share one libamdhip64 instance
+
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

@@ -18,6 +18,30 @@ class HipKernelError(RuntimeError):
     pass
 
 
+# Optional per-launch timing (bench.py roofline leg): when a list is installed here, the contraction
+# and attention wrappers bracket their launch with events on the launching stream and append
+# (kind, flops, start_event, end_event).
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+        return False
+
+
 def _check(rc: int, what: str) -> None:
     if rc != 0:
         raise HipKernelError(f"{what} failed (rc={rc}): {last_error()}")
@@ -63,7 +87,9 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
     d.oscale, d.geglu, d.n_store = oscale, int(geglu), n_store
     d.d, d.ldd = _f16(out, "out").data_ptr(), int(ldd if ldd is not None else (n_store or nout))
     d.zero_page = zero_page(a.device).data_ptr()
-    _check(load().sp_gemm_f16(ctypes.byref(d), _stream()), "sp_gemm_f16")
+    taps = 9 if mode == A_CONV3X3 else 3 if mode == A_TEMPORAL3 else 1
+    with _Timed("gemm", 2.0 * m * n * taps * cin):
+        _check(load().sp_gemm_f16(ctypes.byref(d), _stream()), "sp_gemm_f16")
     return out
 
 
@@ -96,9 +122,10 @@ def layernorm(x, gamma, beta, y, *, rows, c, eps=1e-5, addvec=None, addvec_rows=
 
 
 def attn_spatial(q, k, v, o, *, ldq, ldk, ldv, ldo, batch, seq, heads, scale=0.125):
-    _check(load().sp_attn_spatial_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), ldq, ldk, ldv, ldo,
-                                      batch, seq, heads, scale, zero_page(o.device).data_ptr(), _stream()),
-           "sp_attn_spatial_f16")
+    with _Timed("attn_spatial", 4.0 * batch * heads * seq * seq * 64):
+        _check(load().sp_attn_spatial_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), ldq, ldk, ldv, ldo,
+                                          batch, seq, heads, scale, zero_page(o.device).data_ptr(), _stream()),
+               "sp_attn_spatial_f16")
     return o
 
 
