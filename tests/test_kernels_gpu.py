@@ -42,7 +42,8 @@ def h(t):  # fp16-rounded fp32 copy (what the kernel actually sees)
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (1000, 320, 320), (2016, 1280, 1280), (77, 64, 128),
-                                   (4096, 960, 640), (300, 2560, 320)])
+                                   (4096, 960, 640), (300, 2560, 320), (5000, 256, 64), (8064, 1280, 128),
+                                   (4100, 128, 640), (3000, 128, 192), (3000, 64, 64), (2600, 320, 128)])
 def test_gemm_linear(m, n, k):
     ops = _ops()
     g = torch.Generator().manual_seed(m + n + k)
@@ -75,10 +76,10 @@ def test_gemm_two_residuals_bias2_and_nstore():
     del out
 
 
-def test_gemm_geglu():
+@pytest.mark.parametrize("m,k,inner", [(500, 128, 512), (4500, 192, 256), (3000, 64, 128)])
+def test_gemm_geglu(m, k, inner):
     ops, W = _ops(), _w()
     g = torch.Generator().manual_seed(9)
-    m, k, inner = 500, 128, 512
     a = h(torch.randn(m, k, generator=g)); w = h(torch.randn(2 * inner, k, generator=g) / math.sqrt(k))
     b = torch.randn(2 * inner, generator=g)
     wi, bi = W.interleave_geglu(w, b)
@@ -89,7 +90,7 @@ def test_gemm_geglu():
     check(out, ref)
 
 
-@pytest.mark.parametrize("cin,cout,hh,ww,stride,ups", [(64, 64, 9, 13, 1, 0), (128, 320, 16, 24, 1, 0),
+@pytest.mark.parametrize("cin,cout,hh,ww,stride,ups", [(64, 64, 9, 13, 1, 0), (128, 320, 16, 24, 1, 0), (64, 128, 40, 48, 1, 0),
                                                        (64, 128, 16, 24, 2, 0), (64, 64, 7, 9, 2, 0),
                                                        (128, 64, 6, 10, 1, 1), (320, 320, 18, 32, 1, 0)])
 def test_gemm_conv3x3(cin, cout, hh, ww, stride, ups):
@@ -131,7 +132,7 @@ def test_gemm_conv_in_out_padding():
     check(out2.view(2, 10, 12, 4).permute(0, 3, 1, 2), ref2)
 
 
-@pytest.mark.parametrize("frames,hw,c", [(14, 35, 64), (5, 128, 128), (25, 12, 64)])
+@pytest.mark.parametrize("frames,hw,c", [(14, 35, 64), (5, 128, 128), (25, 12, 64), (14, 200, 128)])
 def test_gemm_temporal_conv(frames, hw, c):
     ops, W = _ops(), _w()
     g = torch.Generator().manual_seed(frames)

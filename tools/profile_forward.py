@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Per-shape timing of one SVD UNet forward (events around every contraction/attention launch)."""
+import os, sys, json, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import vdpp_amd  # noqa
+from vdpp_amd.hip import ops
+from vdpp_amd.models.svd_unet import StableVideoUNet
+
+def main():
+    dev = torch.device("cuda:0")
+    frames = int(os.environ.get("FRAMES", 14))
+    model = StableVideoUNet.from_random_init(StableVideoUNet._default_timestep_schedule(25), seed=0, device=dev)
+    model.set_dummy_conditioning(1, frames, 72, 128, dev)
+    lat = torch.randn(1, 4, frames, 72, 128, device=dev, dtype=torch.float16) * model.init_noise_sigma
+    real_gemm = ops.gemm
+    shapes = []
+    def spy(a, w, out, **kw):
+        shapes.append((kw["m"], kw["n"], kw["cin"], kw.get("mode", 0), bool(kw.get("geglu"))))
+        return real_gemm(a, w, out, **kw)
+    with torch.no_grad():
+        model(lat, 0); model(lat, 1)
+        torch.cuda.synchronize()
+        ops.gemm = spy
+        import vdpp_amd.models.unet_hip as uh
+        ops.PROFILE = []
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record(); model(lat, 2); t1.record()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+    print("forward ms (with event overhead):", t0.elapsed_time(t1))
+    gi = 0
+    agg = collections.OrderedDict()
+    for kind, fl, e0, e1 in prof:
+        ms = e0.elapsed_time(e1)
+        if kind == "gemm":
+            key = ("gemm",) + shapes[gi]; gi += 1
+        else:
+            key = (kind, fl)
+        a = agg.setdefault(key, [0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    tot = sum(v[1] for v in agg.values())
+    print(f"total timed {tot:.2f} ms")
+    for k, (n, ms, fl) in rows[:60]:
+        print(f"{str(k):60s} x{n:3d} {ms:8.3f} ms  {ms/n*1000:9.1f} us/launch  {fl/ms/1e9:8.1f} TF/s")
+
+if __name__ == "__main__":
+    main()

@@ -39,8 +39,21 @@ void sp_set_error(const char *fmt, ...);
   } while (0)
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
-// exact (erf) GELU, as torch F.gelu(approximate="none")
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below fp16 resolution): one rcp, one exp2,
+// six fma – about a third of the instructions of ocml erff, which matters in the GEGLU GEMM epilogue.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  return copysignf(fmaf(-p, e, 1.0f), x);
+}
+// exact-form (erf) GELU, as torch F.gelu(approximate="none")
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

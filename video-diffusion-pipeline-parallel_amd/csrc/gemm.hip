@@ -6,9 +6,14 @@
 //                      the 9 taps are gathered straight from the NHWC tensor (no im2col buffer)
 //   * SP_A_TEMPORAL3 – (3,1,1) convolution over frames; taps are rows m-hw, m, m+hw
 //
-// Structure (per 256-thread workgroup = 4 waves as 2(M) x 2(N)):
-//   tile 128 x BN x 64, BN in {64,128,160}; A and W tiles are brought in by global_load_lds_dwordx4
-//   (LDS-DMA, 1 KiB per wave instruction = 8 rows x 128 B) into a 2-deep LDS ring; the 16-byte
+// Structure: tile BM x BN x 64 per workgroup of WM x WN waves, three shapes chosen on the host:
+//     256 x 128, 8 waves (4x2), 3-deep LDS ring  – large-M contractions (the bulk of the FLOPs); the
+//                 LDS-DMA prefetch runs TWO K-steps ahead and stays in flight across the barrier behind a
+//                 counted s_waitcnt vmcnt(L) (raw s_barrier, never __syncthreads in the loop)
+//     128 x {128,160,64}, 4 waves (2x2), 2-deep ring, 2 workgroups per CU – N = 320/960/1920 and mid sizes
+//      64 x 64, 4 waves, 3-deep ring – the 2016-row level, so that the grid still fills 256 CUs
+//   A and W tiles are brought in by global_load_lds_dwordx4
+//   (LDS-DMA, 1 KiB per wave instruction = 8 rows x 128 B); the 16-byte
 //   chunk index is XOR-swizzled on the *source* address ((row>>1)&7) and un-swizzled on the
 //   ds_read_b128, which makes the 16x16x32 operand reads bank-conflict free; MFMA
 //   v_mfma_f32_16x16x32_f16 with the weight tile as the row operand so that each lane ends up with 4
@@ -20,9 +25,12 @@
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BK = 64;
-constexpr int THREADS = 256;
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
 
 struct GemmArgs {
   const f16 *a;
@@ -51,20 +59,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-template <int BN>
-__global__ __launch_bounds__(THREADS, 2) void gemm_f16_kernel(const GemmArgs p) {
-  constexpr int TN = BN / 32;          // 16-row weight sub-tiles per wave (wave covers BN/2 cols)
-  constexpr int TM = 4;                // 16-col activation sub-tiles per wave (wave covers 64 rows)
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM *WN * 64, 2) void gemm_f16_kernel(const GemmArgs p) {
+  constexpr int NW = WM * WN;
+  constexpr int THREADS = NW * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
+  constexpr int TN = WTN / 16;         // 16-row weight sub-tiles per wave
+  constexpr int TM = WTM / 16;         // 16-col activation sub-tiles per wave
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int B_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int B_LOADS = BN / 32;     // glds per thread for the W tile
+  constexpr int A_LOADS = BM / 8 / NW; // glds (8-row pieces) per thread for the A tile
+  constexpr int B_LOADS = BN / 8 / NW; // ... and for the W tile
+  constexpr int L = A_LOADS + B_LOADS; // LDS-DMA instructions per wave per K-step
+  static_assert(A_LOADS * 8 * NW == BM && B_LOADS * 8 * NW == BN, "tile rows must split evenly over waves");
+  static_assert(STAGES == 2 || STAGES == 3, "2- or 3-deep ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   const int nwg = p.tiles_m * p.tiles_n;
   const int t = xcd_remap(blockIdx.x, nwg);
@@ -76,12 +91,12 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f16_kernel(const GemmArgs p) 
   const int lchunk = lane & 7;                // 16-byte chunk this lane lands in (LDS side)
   const int cpt = p.cin >> 6;                 // K-steps per tap
 
-  int a_i0[4], a_i1[4], a_i2[4];              // conv: img, iy0, ix0 | temporal: frame, -, - | row m
-  bool a_in[4];
-  int schunk_a[4];
+  int a_i0[A_LOADS], a_i1[A_LOADS], a_i2[A_LOADS];   // conv: img, iy0, ix0 | temporal: frame, -, m | -, -, m
+  bool a_in[A_LOADS];
+  int schunk_a[A_LOADS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wave * 32 + i * 8 + lrow;
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int r = (wave * A_LOADS + i) * 8 + lrow;
     const int m = tile_m * BM + r;
     a_in[i] = m < p.m;
     schunk_a[i] = (lchunk ^ ((r >> 1) & 7)) * 8;  // source chunk (halves) for this LDS slot
@@ -102,11 +117,11 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f16_kernel(const GemmArgs p) 
       a_i2[i] = m;
     }
   }
-  const f16 *aptr[4];
-  int astep[4];
+  const f16 *aptr[A_LOADS];
+  int astep[A_LOADS];
   auto set_tap = [&](int tap) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < A_LOADS; ++i) {
       int64_t row = -1;
       if (a_in[i]) {
         if (p.mode == SP_A_CONV3X3) {
@@ -135,7 +150,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f16_kernel(const GemmArgs p) 
   const f16 *bptr[B_LOADS];
 #pragma unroll
   for (int j = 0; j < B_LOADS; ++j) {
-    const int r = wave * (BN / 4) + j * 8 + lrow;
+    const int r = (wave * B_LOADS + j) * 8 + lrow;
     const int n = tile_n * BN + r;
     bptr[j] = p.w + (int64_t)n * p.k + (lchunk ^ ((r >> 1) & 7)) * 8;
   }
@@ -144,13 +159,13 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f16_kernel(const GemmArgs p) 
     char *sa = smem + buf * STAGE;
     char *sb = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(aptr[i], sa + (wave * 32 + i * 8) * 128);
+    for (int i = 0; i < A_LOADS; ++i) {
+      glds16(aptr[i], sa + (wave * A_LOADS + i) * 1024);
       aptr[i] += astep[i];
     }
 #pragma unroll
     for (int j = 0; j < B_LOADS; ++j) {
-      glds16(bptr[j], sb + (wave * (BN / 4) + j * 8) * 128);
+      glds16(bptr[j], sb + (wave * B_LOADS + j) * 1024);
       bptr[j] += BK;
     }
   };
@@ -167,31 +182,31 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f16_kernel(const GemmArgs p) 
   // fragment byte offsets inside a stage (row*128 + swizzled chunk), chunk = ks*4 + fq
   int offw[TN], offa[TM];
 #pragma unroll
-  for (int i = 0; i < TN; ++i) offw[i] = (wn * (BN / 2) + i * 16 + fr) * 128;
+  for (int i = 0; i < TN; ++i) offw[i] = (wn * WTN + i * 16 + fr) * 128;
 #pragma unroll
-  for (int j = 0; j < TM; ++j) offa[j] = (wm * 64 + j * 16 + fr) * 128;
+  for (int j = 0; j < TM; ++j) offa[j] = (wm * WTM + j * 16 + fr) * 128;
   // (row>>1)&7 of the fragment rows: rows are base16 + fr with base16 % 16 == 0
   const int swz = (fr >> 1) & 7;
 
+  // K-steps are staged through a STAGES-deep ring; `staged` counts K-steps whose LDS-DMA has been issued.
+  int staged = 0, in_tap = 0, tap = 0;
+  auto stage_next = [&]() {
+    if (in_tap == cpt) { ++tap; in_tap = 0; set_tap(tap); }
+    stage(staged % STAGES);
+    ++staged; ++in_tap;
+  };
   set_tap(0);
-  stage(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) stage_next();
+  // K-step 0 must have landed; with a 3-deep ring K-step 1 may stay in flight
+  if (STAGES == 3 && nk > 1) wait_vm_lgkm<L>(); else wait_vm_lgkm<0>();
+  __builtin_amdgcn_s_barrier();
 
-  int cur = 0;
-  int in_tap = 1;  // K-steps already staged within the current tap
-  int tap = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      if (in_tap == cpt) {
-        ++tap;
-        in_tap = 0;
-        set_tap(tap);
-      }
-      stage(cur ^ 1);
-      ++in_tap;
-    }
-    const char *sa = smem + cur * STAGE;
+    const bool more = kt + STAGES - 1 < nk;
+    if (more) stage_next();
+    const char *sa = smem + (kt % STAGES) * STAGE;
     const char *sb = sa + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -207,13 +222,15 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f16_kernel(const GemmArgs p) 
         for (int j = 0; j < TM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
+    // K-step kt+1 must be in LDS before the next iteration reads it; the K-step issued this iteration
+    // (3-deep ring) stays in flight across the barrier.  lgkmcnt(0): this wave's reads of slot kt are done
+    // before any wave may overwrite it.
+    if (STAGES == 3 && more) wait_vm_lgkm<L>(); else wait_vm_lgkm<0>();
+    __builtin_amdgcn_s_barrier();
   }
 
   // ---------------------------------------------------------------- epilogue
-  // acc[i][j][r]: n = tile_n*BN + wn*BN/2 + i*16 + 4*fq + r ; m = tile_m*BM + wm*64 + j*16 + fr
+  // acc[i][j][r]: n = tile_n*BN + wn*WTN + i*16 + 4*fq + r ; m = tile_m*BM + wm*WTM + j*16 + fr
   constexpr int BNO_FULL = BN;
   const int bno = p.geglu ? BN / 2 : BNO_FULL;   // output columns of this tile
   const int ldc = bno + 8;                        // halves, padded
@@ -222,13 +239,13 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f16_kernel(const GemmArgs p) 
   if (!p.geglu) {
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      const int nl = wn * (BN / 2) + i * 16 + 4 * fq;
+      const int nl = wn * WTN + i * 16 + 4 * fq;
       const int n = tile_n * BN + nl;
       f32x4 b = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) b = *(const f32x4 *)(p.bias + n);
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        const int ml = wm * 64 + j * 16 + fr;
+        const int ml = wm * WTM + j * 16 + fr;
         f32x4 v = acc[i][j] + b;
         if (p.bias2) {
           const int64_t m = (int64_t)tile_m * BM + ml;
@@ -241,20 +258,20 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f16_kernel(const GemmArgs p) 
       }
     }
   } else {
-    if constexpr (TN % 2 == 0 && (BN / 2) % 32 == 0) {
+    if constexpr (TN % 2 == 0 && WTN % 32 == 0) {
 #pragma unroll
       for (int i = 0; i < TN; i += 2) {
-        const int nl = wn * (BN / 2) + i * 16 + 4 * fq;   // h rows; gate rows are nl + 16
+        const int nl = wn * WTN + i * 16 + 4 * fq;   // h rows; gate rows are nl + 16
         const int n = tile_n * BN + nl;
         f32x4 bh = {0.f, 0.f, 0.f, 0.f}, bg = bh;
         if (p.bias) {
           bh = *(const f32x4 *)(p.bias + n);
           bg = *(const f32x4 *)(p.bias + n + 16);
         }
-        const int ol = (wn * (BN / 2) + i * 16) / 2 + 4 * fq;  // output column within tile
+        const int ol = (wn * WTN + i * 16) / 2 + 4 * fq;  // output column within tile
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-          const int ml = wm * 64 + j * 16 + fr;
+          const int ml = wm * WTM + j * 16 + fr;
           const f32x4 hv = acc[i][j] + bh, gv = acc[i + 1][j] + bg;
           f16x4 h;
 #pragma unroll
@@ -301,17 +318,21 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f16_kernel(const GemmArgs p) 
   }
 }
 
-template <int BN>
-int launch(const GemmArgs &a, hipStream_t s) {
-  constexpr size_t lds = 2 * (BM * BK * 2 + BN * BK * 2);
+template <int BM, int BN, int WM, int WN, int STAGES>
+int launch(GemmArgs &a, hipStream_t s) {
+  constexpr size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
+  static_assert((size_t)BM * (BN + 8) * 2 <= lds, "epilogue staging tile must fit in the ring");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)gemm_f16_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
+    (void)hipFuncSetAttribute((const void *)gemm_f16_kernel<BM, BN, WM, WN, STAGES>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  a.tiles_m = (a.m + BM - 1) / BM;
+  a.tiles_n = a.n / BN;
   SP_CLEAR_STALE_ERROR();
-  hipLaunchKernelGGL(gemm_f16_kernel<BN>, dim3(a.tiles_m * a.tiles_n), dim3(THREADS), lds, s, a);
+  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, STAGES>), dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64),
+                     lds, s, a);
   SP_CHECK_LAUNCH("sp_gemm_f16");
   return SP_OK;
 }
@@ -359,10 +380,11 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
     a.frames = d->frames; a.hw = d->hw;
   }
   if (d->geglu) SP_REQUIRE(d->n % 128 == 0, "sp_gemm_f16: geglu needs n %% 128 == 0");
-  a.tiles_m = (d->m + BM - 1) / BM;
   hipStream_t s = (hipStream_t)stream;
-  if (d->n % 128 == 0) { a.tiles_n = d->n / 128; return launch<128>(a, s); }
-  if (d->n % 160 == 0) { a.tiles_n = d->n / 160; return launch<160>(a, s); }
-  a.tiles_n = d->n / 64;
-  return launch<64>(a, s);
+  const bool n128 = d->n % 128 == 0;
+  if (d->m <= 2560) return launch<64, 64, 2, 2, 3>(a, s);   // few rows: small tiles so the grid fills the chip
+  if (n128 && d->m >= 4096) return launch<256, 128, 4, 2, 3>(a, s);
+  if (n128) return launch<128, 128, 2, 2, 2>(a, s);
+  if (d->n % 160 == 0) return launch<128, 160, 2, 2, 2>(a, s);
+  return launch<128, 64, 2, 2, 2>(a, s);
 }

@@ -35,6 +35,7 @@ Extension field (not in the reference): ``PipelineConfig.balanced`` selects
 from __future__ import annotations
 
 import logging
+import os
 import time
 from collections import deque
 from collections.abc import Sequence
@@ -104,7 +105,12 @@ class _SideStreamLink:
             return
         buf = self._ring[self._slot]
         self._slot ^= 1
+        # WAR fence: the slot's previous latent was consumed by kernels already enqueued on the compute
+        # stream; the incoming message must not land before they have run.
+        consumed = torch.cuda.Event()
+        consumed.record(torch.cuda.current_stream(self.spec.device))
         with torch.cuda.stream(self.stream):
+            self.stream.wait_event(consumed)
             work = dist.irecv(buf, src=self.rank - 1, tag=self.tag)
         self._pending = (work, buf)
 
@@ -159,6 +165,8 @@ class PipelineStage:
             rank=config.rank,
         )
         use_async = config.async_comm
+        if use_async is None and os.environ.get("VDPP_ASYNC_COMM", "1") == "0":
+            use_async = False  # escape hatch: reference-style blocking send/recv on the compute stream
         if use_async is None:
             use_async = (
                 config.latent_spec.device.type == "cuda"
