@@ -160,3 +160,26 @@ def test_init_is_idempotent_and_finalize_safe():
         assert torch.distributed.is_initialized()
         finalize_distributed()
         assert not torch.distributed.is_initialized()
+
+
+def test_simulator_cli_is_reproducible_across_world_sizes(tmp_path):
+    """python -m vdpp_amd.modes.simulator under torchrun: same final norm for 1 and 2 ranks (the reference CLI
+    is not reproducible because it builds the model unseeded; this one seeds every rank)."""
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    entry = tmp_path / "sim.py"
+    entry.write_text("import sys; sys.path.insert(0, %r); import vdpp_amd\n"
+                     "from vdpp_amd.modes import simulator; simulator.main(sys.argv[1:])\n" % root)
+    norms = []
+    for ws, port in ((1, 29541), (2, 29542)):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ws),
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), str(entry), "--total-steps", "8"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        m = re.search(r"Final latent norm: ([0-9.eE+-]+)", r.stderr + r.stdout)
+        assert m, r.stderr[-2000:]
+        norms.append(float(m.group(1)))
+    assert norms[0] == norms[1]
