@@ -57,6 +57,59 @@ def test_gemm_linear(m, n, k):
     check(out, ref)
 
 
+@pytest.fixture
+def force_large_tiles(monkeypatch):
+    monkeypatch.setenv("SP_GEMM_FORCE", "2")   # route eligible shapes through gemm_pp.hip (256x256 / 256x320 tiles)
+
+
+@pytest.mark.parametrize("m,n,k", [(1024, 256, 64), (700, 512, 192), (3000, 320, 64), (2049, 960, 192), (5000, 1280, 128)])
+def test_gemm_large_tile_linear(force_large_tiles, m, n, k):
+    ops = _ops()
+    g = torch.Generator().manual_seed(m + n + k)
+    a = h(torch.randn(m, k, generator=g)); w = h(torch.randn(n, k, generator=g) / math.sqrt(k))
+    bias = torch.randn(n, generator=g); b2 = torch.randn(2, n, generator=g)
+    res = h(torch.randn(m, n, generator=g)); res2 = h(torch.randn(m, n, generator=g))
+    out = torch.empty(m, n, dtype=torch.float16, device=DEV)
+    half_rows = (m + 1) // 2
+    ops.gemm(a.half().to(DEV), w.half().to(DEV), out, m=m, n=n, cin=k, bias=bias.to(DEV), bias2=b2.to(DEV),
+             bias2_rows=half_rows, res1=res.half().to(DEV), r1scale=0.5, res2=res2.half().to(DEV), r2scale=-0.25, oscale=2.0)
+    ref = 2.0 * (a @ w.t() + bias + b2.repeat_interleave(half_rows, 0)[:m]) + 0.5 * res - 0.25 * res2
+    check(out, ref)
+
+
+def test_gemm_large_tile_geglu_conv_temporal(force_large_tiles):
+    ops, W = _ops(), _w()
+    g = torch.Generator().manual_seed(77)
+    # geglu
+    m, k, inner = 1500, 128, 256
+    a = h(torch.randn(m, k, generator=g)); w = h(torch.randn(2 * inner, k, generator=g) / math.sqrt(k)); b = torch.randn(2 * inner, generator=g)
+    wi, bi = W.interleave_geglu(w, b)
+    out = torch.empty(m, inner, dtype=torch.float16, device=DEV)
+    ops.gemm(a.half().to(DEV), wi.to(DEV), out, m=m, n=2 * inner, cin=k, bias=bi.to(DEV), geglu=True)
+    y = a @ w.t() + b
+    check(out, y[:, :inner] * F.gelu(y[:, inner:]))
+    # conv3x3 (stride 1 and the fused x2 upsample), 320 and 256 output channels
+    for cin, cout, hh, ww, ups in ((64, 320, 20, 28, 0), (96, 256, 9, 11, 1)):
+        x = h(torch.randn(3, cin, hh, ww, generator=g)); wc = h(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)); bc = torch.randn(cout, generator=g)
+        xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+        ref = F.conv2d(xin, wc, bc, padding=1)
+        ho, wo = ref.shape[2:]
+        cpad = W.round_up(cin, 64)
+        xp = torch.zeros(3, hh, ww, cpad); xp[..., :cin] = x.permute(0, 2, 3, 1)
+        o = torch.empty(3 * ho * wo, cout, dtype=torch.float16, device=DEV)
+        ops.gemm(xp.half().to(DEV), W.pack_conv3x3(wc).to(DEV), o, m=3 * ho * wo, n=W.round_up(cout, 64), cin=cpad, mode=ops.A_CONV3X3,
+                 conv=(3, hh, ww, ho, wo, 1, ups), bias=bc.to(DEV), ldd=cout)
+        check(o.view(3, ho, wo, cout).permute(0, 3, 1, 2), ref)
+    # temporal conv
+    frames, hw, c = 14, 90, 256
+    x = h(torch.randn(1, c, frames, hw, 1, generator=g)); wt = h(torch.randn(c, c, 3, 1, 1, generator=g) / math.sqrt(3 * c)); bt = torch.randn(c, generator=g)
+    ref = F.conv3d(x, wt, bt, padding=(1, 0, 0))
+    rows = x[..., 0].permute(0, 2, 3, 1).reshape(frames * hw, c).contiguous()
+    o = torch.empty_like(rows, dtype=torch.float16, device=DEV)
+    ops.gemm(rows.half().to(DEV), W.pack_tconv3(wt).to(DEV), o, m=rows.shape[0], n=c, cin=c, mode=ops.A_TEMPORAL3, temporal=(frames, hw), bias=bt.to(DEV))
+    check(o.view(1, frames, hw, c).permute(0, 3, 1, 2), ref[..., 0])
+
+
 def test_gemm_two_residuals_bias2_and_nstore():
     ops = _ops()
     g = torch.Generator().manual_seed(5)
@@ -140,7 +193,7 @@ def test_gemm_temporal_conv(frames, hw, c):
     x = h(torch.randn(bsz, c, frames, hw, 1, generator=g))
     w = h(torch.randn(c, c, 3, 1, 1, generator=g) / math.sqrt(3 * c)); b = torch.randn(c, generator=g)
     ref = F.conv3d(x, w, b, padding=(1, 0, 0))                        # (B,C,F,hw,1)
-    rows = x[..., 0].permute(0, 2, 3, 1).reshape(bsz * frames * hw, c)   # [(b,f,p)][c]
+    rows = x[..., 0].permute(0, 2, 3, 1).reshape(bsz * frames * hw, c).contiguous()   # [(b,f,p)][c]
     out = torch.empty_like(rows, dtype=torch.float16, device=DEV)
     ops.gemm(rows.half().to(DEV), W.pack_tconv3(w).to(DEV), out, m=rows.shape[0], n=c, cin=c,
              mode=ops.A_TEMPORAL3, temporal=(frames, hw), bias=b.to(DEV))

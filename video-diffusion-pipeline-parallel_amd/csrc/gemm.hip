@@ -21,43 +21,13 @@
 //   Out-of-image taps / rows past M read a zero page, so no branch sits in the main loop.
 //   The workgroup -> tile map is XCD-aware: the 8 XCDs each walk a contiguous run of tiles with N
 //   fastest, so an A tile is fetched from HBM once per XCD L2 and re-used by all N tiles.
-#include "common.h"
+#include "gemm_args.h"
+#include <stdlib.h>
+
+using namespace spgemm;
 
 namespace {
 
-constexpr int BK = 64;
-
-template <int N>
-__device__ __forceinline__ void wait_vm_lgkm() {
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-}
-
-struct GemmArgs {
-  const f16 *a;
-  const f16 *w;
-  const float *bias;
-  const float *bias2;
-  const f16 *res1;
-  const f16 *res2;
-  f16 *d;
-  const char *zero;
-  int64_t lda, ldr1, ldr2, ldd, hw, bias2_rows, ldb2;
-  int mode, cin, taps;
-  int n_img, hin, win, hout, wout, stride, ups;
-  int frames;
-  int m, n, k;
-  float oscale, r1scale, r2scale;
-  int geglu, n_store;
-  int tiles_m, tiles_n;
-};
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  // bijective "each XCD gets a contiguous run" remap (blocks b and b+8 share an XCD)
-  const int q = nwg >> 3, r = nwg & 7;
-  const int xcd = bid & 7;
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + (bid >> 3);
-}
 
 template <int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_f16_kernel(const GemmArgs p) {
@@ -81,10 +51,19 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_f16_kernel(const GemmArgs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
+  // XCD-aware, L2-friendly rasterisation: each XCD walks a contiguous run of tile ids, and ids are grouped
+  // GM M-tiles x all N-tiles (column by column), so the ~32-64 workgroups an XCD runs at once form a
+  // GM x (conc/GM) patch: per K-step the patch shares GM A-tiles and conc/GM W-tiles through that XCD's L2.
+  constexpr int GM = BM >= 256 ? 4 : 8;
   const int nwg = p.tiles_m * p.tiles_n;
   const int t = xcd_remap(blockIdx.x, nwg);
-  const int tile_m = t / p.tiles_n;
-  const int tile_n = t - tile_m * p.tiles_n;
+  const int per_group = GM * p.tiles_n;
+  const int group = t / per_group;
+  const int first_m = group * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int in_group = t - group * per_group;
+  const int tile_n = in_group / gsz;
+  const int tile_m = first_m + (in_group - tile_n * gsz);
 
   // ---------------------------------------------------------------- per-lane gather state
   const int lrow = lane >> 3;                 // row within the 8-row glds piece
@@ -203,30 +182,86 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_f16_kernel(const GemmArgs
   if (STAGES == 3 && nk > 1) wait_vm_lgkm<L>(); else wait_vm_lgkm<0>();
   __builtin_amdgcn_s_barrier();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + STAGES - 1 < nk;
-    if (more) stage_next();
-    const char *sa = smem + (kt % STAGES) * STAGE;
-    const char *sb = sa + A_BYTES;
+  if constexpr (NW == 8 && STAGES == 3) {
+    // ---- ping-pong schedule (8 waves = two waves per SIMD; waves w and w+4 share a SIMD) ------------------
+    // Every K-step is split into a READ phase (issue the LDS-DMA prefetch for K-step kt+2, pull all 16 operand
+    // fragments of K-step kt into registers) and a COMPUTE phase (32 MFMAs from registers), separated by
+    // workgroup barriers.  Waves 4-7 run half a K-step behind waves 0-3 (one extra barrier up front), so on
+    // every SIMD one wave is always in its MFMA phase while its partner reads LDS: the matrix pipe does not idle
+    // during operand fetch.  Both halves retire K-step kt+1's DMA (counted vmcnt, K-step kt+2 stays in flight)
+    // before the barrier that precedes the first read of it.
+    const bool late = wave >= 4;
+    if (late) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 2 < nk;
+      if (more && !(p.dbg & 1)) stage_next();
+      const char *sa = smem + (kt % 3) * STAGE;
+      const char *sb = sa + A_BYTES;
+      f16x8 fw[2][TN], fa[2][TM];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int coff = ((ks * 4 + fq) ^ swz) << 4;
-      f16x8 fw[TN], fa[TM];
+      for (int ks = 0; ks < 2; ++ks) {
+        const int coff = ((ks * 4 + fq) ^ swz) << 4;
 #pragma unroll
-      for (int i = 0; i < TN; ++i) fw[i] = *(const f16x8 *)(sb + offw[i] + coff);
+        for (int i = 0; i < TN; ++i) fw[ks][i] = *(const f16x8 *)(sb + offw[i] + coff);
 #pragma unroll
-      for (int j = 0; j < TM; ++j) fa[j] = *(const f16x8 *)(sa + offa[j] + coff);
+        for (int j = 0; j < TM; ++j) fa[ks][j] = *(const f16x8 *)(sa + offa[j] + coff);
+      }
+      if (late) { if (more) wait_vm_lgkm<L>(); else wait_vm_lgkm<0>(); }
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      if (!(p.dbg & 2)) {
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(fw[ks][i]));
+#pragma unroll
+          for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(fa[ks][j]));
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (!late) { if (more) wait_vm_lgkm<L>(); else wait_vm_lgkm<0>(); }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // K-step kt+1 must be in LDS before the next iteration reads it; the K-step issued this iteration
-    // (3-deep ring) stays in flight across the barrier.  lgkmcnt(0): this wave's reads of slot kt are done
-    // before any wave may overwrite it.
-    if (STAGES == 3 && more) wait_vm_lgkm<L>(); else wait_vm_lgkm<0>();
-    __builtin_amdgcn_s_barrier();
+    if (!late) __builtin_amdgcn_s_barrier();
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + STAGES - 1 < nk;
+      if (more) stage_next();
+      const char *sa = smem + (kt % STAGES) * STAGE;
+      const char *sb = sa + A_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int coff = ((ks * 4 + fq) ^ swz) << 4;
+        f16x8 fw[TN], fa[TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fw[i] = *(const f16x8 *)(sb + offw[i] + coff);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) fa[j] = *(const f16x8 *)(sa + offa[j] + coff);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+      }
+      // K-step kt+1 must be in LDS before the next iteration reads it; the K-step issued this iteration
+      // (3-deep ring) stays in flight across the barrier.  lgkmcnt(0): this wave's reads of slot kt are done
+      // before any wave may overwrite it.
+      if (STAGES == 3 && more) wait_vm_lgkm<L>(); else wait_vm_lgkm<0>();
+      __builtin_amdgcn_s_barrier();
+    }
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -349,6 +384,7 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   SP_REQUIRE(d->lda >= d->cin && d->lda % 8 == 0, "sp_gemm_f16: lda=%lld invalid", (long long)d->lda);
   SP_REQUIRE(d->ldd % 8 == 0 || d->n_store > 0, "sp_gemm_f16: ldd must be a multiple of 8");
   GemmArgs a{};
+  { const char *e = getenv("SP_GEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.a = (const f16 *)d->a; a.w = (const f16 *)d->w; a.bias = d->bias; a.bias2 = d->bias2;
   a.res1 = (const f16 *)d->res1; a.res2 = (const f16 *)d->res2; a.d = (f16 *)d->d;
   a.zero = (const char *)d->zero_page;
@@ -383,6 +419,25 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool n128 = d->n % 128 == 0;
   if (d->m <= 2560) return launch<64, 64, 2, 2, 3>(a, s);   // few rows: small tiles so the grid fills the chip
+  {
+    // large ping-pong tiles (gemm_pp.hip) for every N that is a multiple of 256 or 320
+    const char *fe = getenv("SP_GEMM_FORCE");   // experiments/tests: 1 = never, 2 = always use the large tiles
+    const int force = fe ? atoi(fe) : 0;
+    const char *be = getenv("SP_GEMM_BN");      // experiments: force 256 or 320
+    const int tm = (d->m + 255) / 256;
+    const bool ok256 = d->n % 256 == 0, ok320 = d->n % 320 == 0 && !d->geglu;
+    if (force != 1 && (ok256 || ok320)) {
+      int bn = ok256 ? 256 : 320;
+      if (ok256 && ok320) {
+        // both divide N: take the one that wastes less of the last round of workgroups over 256 CUs
+        const int b256 = tm * (d->n / 256), b320 = tm * (d->n / 320);
+        const double e256 = (double)b256 / (((b256 + 255) / 256) * 256), e320 = (double)b320 / (((b320 + 255) / 256) * 256);
+        bn = e320 > e256 + 0.02 ? 320 : 256;
+      }
+      if (be) { const int want = atoi(be); if ((want == 256 && ok256) || (want == 320 && ok320)) bn = want; }
+      return bn == 256 ? launch_pp256(a, s) : launch_pp320(a, s);
+    }
+  }
   if (n128 && d->m >= 4096) return launch<256, 128, 4, 2, 3>(a, s);
   if (n128) return launch<128, 128, 2, 2, 2>(a, s);
   if (d->n % 160 == 0) return launch<128, 160, 2, 2, 2>(a, s);

@@ -1,0 +1,47 @@
+// Shared by the implicit-GEMM kernels (gemm.hip, gemm_pp.hip).
+#pragma once
+#include "common.h"
+
+namespace spgemm {
+
+constexpr int BK = 64;
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+struct GemmArgs {
+  const f16 *a;
+  const f16 *w;
+  const float *bias;
+  const float *bias2;
+  const f16 *res1;
+  const f16 *res2;
+  f16 *d;
+  const char *zero;
+  int64_t lda, ldr1, ldr2, ldd, hw, bias2_rows, ldb2;
+  int mode, cin, taps;
+  int n_img, hin, win, hout, wout, stride, ups;
+  int frames;
+  int m, n, k;
+  float oscale, r1scale, r2scale;
+  int geglu, n_store;
+  int tiles_m, tiles_n;
+  int dbg;   // timing experiments only (SP_GEMM_DBG): 1 = no LDS-DMA in the loop, 2 = no MFMA
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // bijective "each XCD gets a contiguous run" remap (blocks b and b+8 share an XCD)
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+
+// BM=256 ping-pong kernels (gemm_pp.hip); returns SP_OK / SP_ELAUNCH
+int launch_pp256(GemmArgs &a, hipStream_t s);
+int launch_pp320(GemmArgs &a, hipStream_t s);
+
+}  // namespace spgemm

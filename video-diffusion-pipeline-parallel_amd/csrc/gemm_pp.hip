@@ -1,0 +1,368 @@
+// Large-tile implicit-GEMM for gfx950: 256 x BN x 32 per workgroup (BN = 256 or 320), 8 waves as 2(M) x 4(N),
+// 4-deep LDS ring, ping-pong schedule.  Same contract and epilogue as gemm.hip (see there for the operand
+// gather and the swizzle idea); this variant exists because the per-CU L2->LDS path (~64 B/clk) feeds a
+// 256x128 tile only ~1.0 PFLOP/s worth of operands: a 256x256 (256x320) tile needs half (0.44x) the bytes per
+// FLOP, and every N of the SVD UNet is a multiple of 256 or 320.
+//
+// Schedule.  One K-step is 32 channels: 32 KB (36 KB) of operands, 32 (40) MFMAs per wave.  Each K-step of a
+// wave is a READ phase (issue the LDS-DMA for K-step k+3, ds_read the 12 (13) operand fragments of K-step k)
+// followed by a COMPUTE phase (the MFMAs, operands in registers), with a workgroup barrier after each phase.
+// Waves 4-7 run one phase behind waves 0-3 (they share SIMDs pairwise: w and w+4), so on every SIMD one wave is
+// in its MFMA phase while the other fetches operands.  LDS-DMA stays in flight across barriers behind counted
+// s_waitcnt vmcnt (K-steps k+2 and k+3 outstanding while k+1 is retired one phase before its first read).
+//
+// LDS image per stage: rows of 64 B (32 halves), 16-byte chunk c of row r stored at chunk c ^ S[(r>>2)&3],
+// S = {0,2,3,1}: makes the ds_read_b128 of a 16x16x32 operand (16 rows x one chunk per 16-lane group)
+// bank-conflict free; applied on the DMA *source* address, undone in the read address.
+#include "gemm_args.h"
+
+namespace spgemm {
+namespace {
+
+constexpr int PBM = 256, PBK = 32, PSTAGES = 4, PDIST = 3, PNW = 8;
+
+__device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// waits until at most `ksteps_left` K-steps of this wave's DMA (L instructions each) are outstanding
+template <int L>
+__device__ __forceinline__ void wait_dma(int ksteps_left) {
+  if (ksteps_left >= 2) wait_vm<2 * L>();
+  else if (ksteps_left == 1) wait_vm<L>();
+  else wait_vm<0>();
+}
+
+template <int BN, int EXP>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
+  constexpr int TN = BN / 4 / 16;                 // weight sub-tiles per wave (4 or 5)
+  constexpr int TM = 8;                           // activation sub-tiles per wave (128 rows)
+  constexpr int WTN = BN / 4, WTM = 128;
+  constexpr int A_BYTES = PBM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_LOADS = 2;                      // 16 pieces of 16 rows over 8 waves
+  constexpr int B_PIECES = BN / 16;               // 16 or 20
+  constexpr int B_LOADS_LO = (B_PIECES + 7) / 8;  // waves 0..(B_PIECES%8 - 1) (all waves if divisible)
+  constexpr int B_LOADS_HI = B_PIECES / 8;        // the other waves
+  constexpr int B_SPLIT = B_PIECES % 8 == 0 ? 8 : B_PIECES % 8;   // waves below this index take B_LOADS_LO
+  static_assert(B_SPLIT == 8 || B_SPLIT == 4, "wave halves must have uniform DMA counts");
+  constexpr int L_EARLY = A_LOADS + B_LOADS_LO;   // waves 0-3
+  constexpr int L_LATE = A_LOADS + (B_SPLIT == 8 ? B_LOADS_LO : B_LOADS_HI);   // waves 4-7
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const bool late = wave >= 4;
+
+  constexpr int GM = 4;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nwg);
+  const int per_group = GM * p.tiles_n;
+  const int group = t / per_group;
+  const int first_m = group * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int in_group = t - group * per_group;
+  const int tile_n = in_group / gsz;
+  const int tile_m = first_m + (in_group - tile_n * gsz);
+
+  // ---------------------------------------------------------------- per-lane gather state
+  const int lrow = lane >> 2, lchunk = lane & 3;  // 16 rows x 4 chunks per 1-KiB piece
+  const int cpt = p.cin >> 5;                     // K-steps per tap
+
+  int a_i0[A_LOADS], a_i1[A_LOADS], a_i2[A_LOADS];
+  bool a_in[A_LOADS];
+  int schunk_a[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int r = (wave * A_LOADS + i) * 16 + lrow;
+    const int m = tile_m * PBM + r;
+    a_in[i] = m < p.m;
+    schunk_a[i] = (lchunk ^ swz4(r)) * 8;
+    if (p.mode == SP_A_CONV3X3) {
+      const int per_img = p.hout * p.wout;
+      const int img = m / per_img;
+      const int rem = m - img * per_img;
+      const int oy = rem / p.wout;
+      a_i0[i] = img;
+      a_i1[i] = oy * p.stride - 1;
+      a_i2[i] = (rem - oy * p.wout) * p.stride - 1;
+    } else if (p.mode == SP_A_TEMPORAL3) {
+      a_i0[i] = (int)((m / p.hw) % p.frames);
+      a_i1[i] = 0;
+      a_i2[i] = m;
+    } else {
+      a_i0[i] = a_i1[i] = 0;
+      a_i2[i] = m;
+    }
+  }
+  const f16 *aptr[A_LOADS];
+  int astep[A_LOADS];
+  auto set_tap = [&](int tap) {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      int64_t row = -1;
+      if (a_in[i]) {
+        if (p.mode == SP_A_CONV3X3) {
+          const int ky = tap / 3, kx = tap - ky * 3;
+          const int iy = a_i1[i] + ky, ix = a_i2[i] + kx;
+          const int hv = p.hin << p.ups, wv = p.win << p.ups;
+          if (iy >= 0 && iy < hv && ix >= 0 && ix < wv)
+            row = ((int64_t)a_i0[i] * p.hin + (iy >> p.ups)) * p.win + (ix >> p.ups);
+        } else if (p.mode == SP_A_TEMPORAL3) {
+          const int f = a_i0[i] + tap - 1;
+          if (f >= 0 && f < p.frames) row = (int64_t)a_i2[i] + (int64_t)(tap - 1) * p.hw;
+        } else {
+          row = a_i2[i];
+        }
+      }
+      if (row >= 0) {
+        aptr[i] = p.a + row * p.lda + schunk_a[i];
+        astep[i] = PBK;
+      } else {
+        aptr[i] = (const f16 *)(p.zero + lchunk * 16);
+        astep[i] = 0;
+      }
+    }
+  };
+
+  // W pieces: piece index = j*8 + wave (j < B_LOADS_LO; the last j only exists for waves < B_SPLIT)
+  const f16 *bptr[B_LOADS_LO];
+#pragma unroll
+  for (int j = 0; j < B_LOADS_LO; ++j) {
+    const int piece = j * 8 + wave;
+    const int r = piece * 16 + lrow;
+    const int n = tile_n * BN + (r < BN ? r : 0);
+    bptr[j] = p.w + (int64_t)n * p.k + (lchunk ^ swz4(r)) * 8;
+  }
+
+  auto stage = [&](int slot) {
+    char *sa = smem + slot * STAGE;
+    char *sb = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      glds16(aptr[i], sa + (wave * A_LOADS + i) * 1024);
+      aptr[i] += astep[i];
+    }
+#pragma unroll
+    for (int j = 0; j < B_LOADS_LO; ++j) {
+      if (j < B_LOADS_HI || wave < B_SPLIT) {     // wave-uniform
+        glds16(bptr[j], sb + (j * 8 + wave) * 1024);
+        bptr[j] += PBK;
+      }
+    }
+  };
+
+  // ---------------------------------------------------------------- main loop
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.k >> 5;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rd_chunk = (fq ^ swz4(fr)) << 4;      // fragment rows are (multiple of 16) + fr
+  int offw[TN], offa[TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) offw[i] = (wn * WTN + i * 16 + fr) * 64 + rd_chunk;
+#pragma unroll
+  for (int j = 0; j < TM; ++j) offa[j] = (wm * WTM + j * 16 + fr) * 64 + rd_chunk;
+
+  int staged = 0, in_tap = 0, tap = 0;
+  auto stage_next = [&]() {
+    if (in_tap == cpt) { ++tap; in_tap = 0; set_tap(tap); }
+    stage(staged & (PSTAGES - 1));
+    ++staged; ++in_tap;
+  };
+  set_tap(0);
+#pragma unroll
+  for (int s = 0; s < PDIST; ++s)
+    if (s < nk) stage_next();
+  // K-step 0 landed (this wave's part), later ones may stay in flight
+  {
+    const int left = min(PDIST - 1, nk - 1);
+    if (late) wait_dma<L_LATE>(left); else wait_dma<L_EARLY>(left);
+  }
+  __builtin_amdgcn_s_barrier();
+  if (late) __builtin_amdgcn_s_barrier();
+
+  constexpr int dbg = EXP;   // timing experiments only (0 in production): 1 no DMA in loop, 2 no MFMA, 64 no ds_read
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- READ phase: operand fragments first, then the LDS-DMA for K-step kt+3.  The DMA instructions
+    // queue behind the CU's single 64 B/clk texture-address path (about 100 cycles each when four waves issue
+    // together); placed after the ds_reads they stall a wave that has nothing left to issue anyway.
+    const bool issue = kt + PDIST < nk;
+    const char *sa = smem + (kt & (PSTAGES - 1)) * STAGE;
+    const char *sb = sa + A_BYTES;
+    f16x8 fw[TN], fa[TM];
+    if (!(dbg & 64) || kt == 0) {  // (dbg is constexpr)
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fw[i] = *(const f16x8 *)(sb + offw[i]);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) fa[j] = *(const f16x8 *)(sa + offa[j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fw[i] = (f16x8){1, 2, 3, 4, 5, 6, 7, (f16)kt};
+#pragma unroll
+      for (int j = 0; j < TM; ++j) fa[j] = (f16x8){1, 2, 3, 4, 5, 6, 7, (f16)lane};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(dbg & 1)) { if (issue) stage_next(); }
+    // K-steps issued beyond kt+1 so far: up to kt+PDIST
+    int left = min(PDIST - 1, nk - 2 - kt);
+    if (left < 0) left = 0;
+    if (late) wait_dma<L_LATE>(left);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- COMPUTE phase
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (!(dbg & 2)) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(fw[i]));
+#pragma unroll
+      for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(fa[j]));
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (!late) wait_dma<L_EARLY>(min(PDIST - 1, max(nk - 2 - kt, 0)));
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!late) __builtin_amdgcn_s_barrier();
+
+  // ---------------------------------------------------------------- epilogue (two 128-row halves)
+  const int bno = p.geglu ? BN / 2 : BN;
+  const int ldc = bno + 8;
+  f16 *sc = (f16 *)smem;
+  const int cpr = bno >> 3;
+  const int ncols_total = p.geglu ? p.n / 2 : p.n;
+  const int nstore = p.n_store > 0 ? p.n_store : ncols_total;
+
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+      if (!p.geglu) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int nl = wn * WTN + i * 16 + 4 * fq;
+          const int n = tile_n * BN + nl;
+          f32x4 b = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias) b = *(const f32x4 *)(p.bias + n);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            const int ml = j * 16 + fr;                      // row within the half
+            f32x4 v = acc[i][j] + b;
+            if (p.bias2) {
+              const int64_t m = (int64_t)tile_m * PBM + half * 128 + ml;
+              const int64_t brow = m < p.m ? m / p.bias2_rows : 0;
+              v += *(const f32x4 *)(p.bias2 + brow * p.ldb2 + n);
+            }
+            v *= p.oscale;
+            f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            *(f16x4 *)(sc + ml * ldc + nl) = h;
+          }
+        }
+      } else {
+        if constexpr (TN % 2 == 0) {
+#pragma unroll
+          for (int i = 0; i < TN; i += 2) {
+            const int nl = wn * WTN + i * 16 + 4 * fq;
+            const int n = tile_n * BN + nl;
+            f32x4 bh = {0.f, 0.f, 0.f, 0.f}, bg = bh;
+            if (p.bias) {
+              bh = *(const f32x4 *)(p.bias + n);
+              bg = *(const f32x4 *)(p.bias + n + 16);
+            }
+            const int ol = (wn * WTN + i * 16) / 2 + 4 * fq;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+              const int ml = j * 16 + fr;
+              const f32x4 hv = acc[i][j] + bh, gv = acc[i + 1][j] + bg;
+              f16x4 h;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) h[r] = (f16)(p.oscale * hv[r] * gelu_f(gv[r]));
+              *(f16x4 *)(sc + ml * ldc + ol) = h;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 128 * cpr; idx += 512) {
+      const int r = idx / cpr, c = idx - r * cpr;
+      const int64_t m = (int64_t)tile_m * PBM + half * 128 + r;
+      if (m >= p.m) continue;
+      const int col = tile_n * bno + c * 8;
+      if (col >= nstore) continue;
+      f16x8 v = *(const f16x8 *)(sc + r * ldc + c * 8);
+      if (p.res1 || p.res2) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+        if (p.res1) {
+          const f16x8 q = *(const f16x8 *)(p.res1 + m * p.ldr1 + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += p.r1scale * (float)q[e];
+        }
+        if (p.res2) {
+          const f16x8 q = *(const f16x8 *)(p.res2 + m * p.ldr2 + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += p.r2scale * (float)q[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (f16)f[e];
+      }
+      if (col + 8 <= nstore) {
+        *(f16x8 *)(p.d + m * p.ldd + col) = v;
+      } else {
+        for (int e = 0; e < nstore - col; ++e) p.d[m * p.ldd + col + e] = v[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int BN, int EXP = 0>
+int launch_pp(GemmArgs &a, hipStream_t s) {
+  constexpr size_t lds = (size_t)PSTAGES * (PBM + BN) * 64;
+  static_assert((size_t)128 * (BN + 8) * 2 <= lds, "half-tile staging must fit in the ring");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)gemm_pp_kernel<BN, EXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  a.tiles_m = (a.m + PBM - 1) / PBM;
+  a.tiles_n = a.n / BN;
+  SP_CLEAR_STALE_ERROR();
+  hipLaunchKernelGGL((gemm_pp_kernel<BN, EXP>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
+  SP_CHECK_LAUNCH("sp_gemm_f16(pp)");
+  return SP_OK;
+}
+
+}  // namespace
+
+int launch_pp256(GemmArgs &a, hipStream_t s) {
+#ifdef SP_GEMM_EXPERIMENTS
+  switch (a.dbg) {
+    case 1: return launch_pp<256, 1>(a, s);
+    case 2: return launch_pp<256, 2>(a, s);
+    case 3: return launch_pp<256, 3>(a, s);
+    case 65: return launch_pp<256, 65>(a, s);
+    case 67: return launch_pp<256, 67>(a, s);
+    default: break;
+  }
+#endif
+  return launch_pp<256>(a, s);
+}
+int launch_pp320(GemmArgs &a, hipStream_t s) { return launch_pp<320>(a, s); }
+
+}  // namespace spgemm

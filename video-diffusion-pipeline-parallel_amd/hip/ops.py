@@ -66,6 +66,16 @@ def zero_page(device) -> torch.Tensor:
 def _f16(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dtype != torch.float16 or not t.is_cuda:
         raise TypeError(f"{name} must be a float16 tensor on a HIP device")
+    if t.dim() >= 1 and t.stride(-1) != 1 and t.shape[-1] != 1:
+        raise ValueError(f"{name} must be row-major (innermost stride 1); got strides {tuple(t.stride())}")
+    return t
+
+
+def _rows(t: torch.Tensor, name: str, ld: int) -> torch.Tensor:
+    """2-D token matrix whose row pitch must equal the leading dimension handed to the kernel."""
+    _f16(t, name)
+    if t.dim() == 2 and t.shape[0] > 1 and t.stride(0) != ld:
+        raise ValueError(f"{name}: row stride {t.stride(0)} does not match leading dimension {ld}")
     return t
 
 
@@ -74,7 +84,8 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
          geglu=False, n_store=0, ldd=None, ldr1=None, ldr2=None):
     """``out[m][:] = epilogue(sum_taps A_tap @ W^T)``; see ``sp_gemm_desc`` in include/svdpipe.h."""
     d = GemmDesc()
-    d.a, d.lda, d.mode, d.cin = _f16(a, "a").data_ptr(), int(lda if lda is not None else cin), mode, cin
+    d.lda = int(lda if lda is not None else cin)
+    d.a, d.mode, d.cin = _rows(a, "a", d.lda).data_ptr(), mode, cin
     if mode == A_CONV3X3:
         d.n_img, d.hin, d.win, d.hout, d.wout, d.stride, d.upsample2x = conv
     if mode == A_TEMPORAL3:
@@ -85,7 +96,8 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
     d.res1, d.ldr1, d.r1scale = _ptr(res1), int(ldr1 if ldr1 is not None else nout), r1scale
     d.res2, d.ldr2, d.r2scale = _ptr(res2), int(ldr2 if ldr2 is not None else nout), r2scale
     d.oscale, d.geglu, d.n_store = oscale, int(geglu), n_store
-    d.d, d.ldd = _f16(out, "out").data_ptr(), int(ldd if ldd is not None else (n_store or nout))
+    d.ldd = int(ldd if ldd is not None else (n_store or nout))
+    d.d = _rows(out, "out", d.ldd).data_ptr()
     d.zero_page = zero_page(a.device).data_ptr()
     taps = 9 if mode == A_CONV3X3 else 3 if mode == A_TEMPORAL3 else 1
     with _Timed("gemm", 2.0 * m * n * taps * cin):
