@@ -29,6 +29,10 @@ __device__ __forceinline__ f16x4 lds_tr16(const char *p) {
 
 constexpr float NEG_BIG = -3.0e38f;
 
+// raw v_exp_f32 (2^x): arguments here are <= 0 and results below 2^-126 may flush to zero, so the
+// range-reduction / denormal wrapper that exp2f() adds (6 extra VALU ops per element) is not needed.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
     const f16 *__restrict__ q, const f16 *__restrict__ k, const f16 *__restrict__ v, f16 *__restrict__ o,
@@ -87,6 +91,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
   const int vchunk_l = 2 * (g & 1) + (pp >> 1);               // + 4*dt
   const int vswz = (q_ >> 1) << 2;
   const int vbyte_l = (pp & 1) * 8;
+  // lane part of the transposed-read address for d-tile 0 / 1; the key offset is a compile-time immediate
+  const int vlane0 = vrow_l * 128 + ((vchunk_l ^ vswz) << 4) + vbyte_l;
+  const int vlane1 = vrow_l * 128 + (((4 + vchunk_l) ^ vswz) << 4) + vbyte_l;
 
   f32x16 oacc[2];
 #pragma unroll
@@ -102,6 +109,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
     if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
     const char *sk = smem + buf * STAGE;
     const char *sv = sk + K_BYTES;
+    const char *sv0 = sv + vlane0, *sv1 = sv + vlane1;
 
     // ---- S^T = K.Q^T : two 32-key sub-tiles
     f32x16 sacc[2];
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);
     if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-      const float alpha = exp2f((m_run - m_new) * scale_log2e);
+      const float alpha = fast_exp2((m_run - m_new) * scale_log2e);
       l_run *= alpha;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pv = exp2f(sacc[kt][e] * scale_log2e - mb);
+        const float pv = fast_exp2(sacc[kt][e] * scale_log2e - mb);
         lsum += pv;
         pf[kt][e >> 3][e & 7] = (f16)pv;
       }
@@ -163,9 +171,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
           f16x8 vf;
 #pragma unroll
           for (int e2 = 0; e2 < 2; ++e2) {
-            const int row = kt * 32 + 16 * s + 8 * e2 + vrow_l;
-            const int chunk = (4 * dt + vchunk_l) ^ vswz;
-            const f16x4 x = lds_tr16(sv + row * 128 + chunk * 16 + vbyte_l);
+            const f16x4 x = lds_tr16((dt ? sv1 : sv0) + (kt * 32 + 16 * s + 8 * e2) * 128);
             vf[4 * e2 + 0] = x[0]; vf[4 * e2 + 1] = x[1]; vf[4 * e2 + 2] = x[2]; vf[4 * e2 + 3] = x[3];
           }
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kt][s], oacc[dt], 0, 0, 0);
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        pv[kt][e] = exp2f(sacc[kt][qt][e] * scale_log2e - mb);
+        pv[kt][e] = fast_exp2(sacc[kt][qt][e] * scale_log2e - mb);
         sum += pv[kt][e];
       }
     sum += __shfl_xor(sum, 16, 64);
