@@ -58,8 +58,8 @@ def parse():
 
 
 def cpu_baseline(frames_full, h, w, total_steps):
-    """Oracle fp32 UNet (plain PyTorch CPU) on a bounded sample: one forward at 2 frames; scaled by the
-    algorithmic FLOP ratio to 14 frames x total_steps."""
+    """Oracle fp32 UNet (plain PyTorch CPU) on a bounded sample: one forward at 4 of 14 frames; scaled by the
+    algorithmic FLOP ratio to 14 frames x total_steps (about 10-20 s of host work)."""
     from oracle.svd_unet_ref import SVDUNetConfig, SVDUNetRef, unet_flops
 
     cores = os.cpu_count() or 1
@@ -72,7 +72,7 @@ def cpu_baseline(frames_full, h, w, total_steps):
     with torch.no_grad():
         for p in ref.parameters():
             p.fill_(0.01)
-    sample_frames = 2
+    sample_frames = 4
     x = torch.randn(1, sample_frames, 8, h, w)
     ctx = torch.randn(1, 1, cfg.cross_attention_dim)
     ids = torch.tensor([[5.0, 127.0, 0.02]])

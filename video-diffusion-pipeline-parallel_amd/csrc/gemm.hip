@@ -418,7 +418,10 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   if (d->geglu) SP_REQUIRE(d->n % 128 == 0, "sp_gemm_f16: geglu needs n %% 128 == 0");
   hipStream_t s = (hipStream_t)stream;
   const bool n128 = d->n % 128 == 0;
-  if (d->m <= 2560) return launch<64, 64, 2, 2, 3>(a, s);   // few rows: small tiles so the grid fills the chip
+  if (d->m <= 2560) {   // few rows (the 2016-row level): small tiles so the grid still covers 256 CUs
+    if (d->n >= 3840 && n128) return launch<128, 128, 2, 2, 2>(a, s);
+    return launch<64, 64, 2, 2, 3>(a, s);
+  }
   {
     // large ping-pong tiles (gemm_pp.hip) for every N that is a multiple of 256 or 320
     const char *fe = getenv("SP_GEMM_FORCE");   // experiments/tests: 1 = never, 2 = always use the large tiles
