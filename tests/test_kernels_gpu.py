@@ -57,9 +57,10 @@ def test_gemm_linear(m, n, k):
     check(out, ref)
 
 
-@pytest.fixture
-def force_large_tiles(monkeypatch):
-    monkeypatch.setenv("SP_GEMM_FORCE", "2")   # route eligible shapes through gemm_pp.hip (256x256 / 256x320 tiles)
+@pytest.fixture(params=[256, 192, 128])
+def force_large_tiles(monkeypatch, request):
+    monkeypatch.setenv("SP_GEMM_FORCE", "2")   # route eligible shapes through gemm_pp.hip (BM x 256 / BM x 320 tiles)
+    monkeypatch.setenv("SP_GEMM_BM", str(request.param))
 
 
 @pytest.mark.parametrize("m,n,k", [(1024, 256, 64), (700, 512, 192), (3000, 320, 64), (2049, 960, 192), (5000, 1280, 128)])

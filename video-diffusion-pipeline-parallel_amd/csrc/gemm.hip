@@ -430,15 +430,24 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
     const int tm = (d->m + 255) / 256;
     const bool ok256 = d->n % 256 == 0, ok320 = d->n % 320 == 0 && !d->geglu;
     if (force != 1 && (ok256 || ok320)) {
-      int bn = ok256 ? 256 : 320;
-      if (ok256 && ok320) {
-        // both divide N: take the one that wastes less of the last round of workgroups over 256 CUs
-        const int b256 = tm * (d->n / 256), b320 = tm * (d->n / 320);
-        const double e256 = (double)b256 / (((b256 + 255) / 256) * 256), e320 = (double)b320 / (((b320 + 255) / 256) * 256);
-        bn = e320 > e256 + 0.02 ? 320 : 256;
-      }
+      // Pick the (BM, BN) whose last round of workgroups wastes the fewest of the 256 CUs (one workgroup per CU);
+      // larger tiles win ties because they move fewer operand bytes per FLOP.
+      int bm = 256, bn = ok256 ? 256 : 320;
+      double best = -1.0;
+      const int bms[2] = {256, 192}, bns[2] = {256, 320};
+      for (int bi = 0; bi < 2; ++bi)
+        for (int ni = 0; ni < 2; ++ni) {
+          if ((bns[ni] == 256 && !ok256) || (bns[ni] == 320 && !ok320)) continue;
+          const int blocks = ((d->m + bms[bi] - 1) / bms[bi]) * (d->n / bns[ni]);
+          double score = (double)blocks / (((blocks + 255) / 256) * 256.0);
+          if (bms[bi] == 192) score -= 0.06;
+          if (bns[ni] == 320) score -= 0.01;
+          if (score > best) { best = score; bm = bms[bi]; bn = bns[ni]; }
+        }
       if (be) { const int want = atoi(be); if ((want == 256 && ok256) || (want == 320 && ok320)) bn = want; }
-      return bn == 256 ? launch_pp256(a, s) : launch_pp320(a, s);
+      const char *me = getenv("SP_GEMM_BM");    // experiments/tests: force 128 / 192 / 256
+      if (me) { const int want = atoi(me); if (want == 192 || want == 256 || (want == 128 && bn == 256)) bm = want; }
+      return launch_pp(a, bm, bn, s);
     }
   }
   if (n128 && d->m >= 4096) return launch<256, 128, 4, 2, 3>(a, s);

@@ -40,8 +40,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 
-// BM=256 ping-pong kernels (gemm_pp.hip); returns SP_OK / SP_ELAUNCH
-int launch_pp256(GemmArgs &a, hipStream_t s);
-int launch_pp320(GemmArgs &a, hipStream_t s);
+// ping-pong large-tile kernels (gemm_pp.hip): bm in {128 (bn 256 only), 192, 256}, bn in {256, 320}
+int launch_pp(GemmArgs &a, int bm, int bn, hipStream_t s);
 
 }  // namespace spgemm

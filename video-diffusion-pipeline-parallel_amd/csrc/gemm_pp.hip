@@ -19,7 +19,7 @@
 namespace spgemm {
 namespace {
 
-constexpr int PBM = 256, PBK = 32, PSTAGES = 4, PDIST = 3, PNW = 8;
+constexpr int PBK = 32, PNW = 8;
 
 __device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
@@ -34,20 +34,28 @@ __device__ __forceinline__ void wait_dma(int ksteps_left) {
   else wait_vm<0>();
 }
 
-template <int BN, int EXP>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
+// BM = 256: one workgroup per CU (4-deep ring).  BM = 192: same, for row counts where 256-row tiles leave a
+// third of the CUs idle in the only round (8064 rows x 1280 columns).  BM = 128: 3-deep ring and <= 128 VGPRs so
+// that TWO workgroups share a CU and one's prologue/epilogue overlaps the other's main loop (short-K GEMMs).
+template <int BM, int BN, int EXP>
+__global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const GemmArgs p) {
+  constexpr int PBM = BM;
+  constexpr int PSTAGES = BM == 128 ? 3 : 4, PDIST = PSTAGES - 1;
   constexpr int TN = BN / 4 / 16;                 // weight sub-tiles per wave (4 or 5)
-  constexpr int TM = 8;                           // activation sub-tiles per wave (128 rows)
-  constexpr int WTN = BN / 4, WTM = 128;
+  constexpr int TM = BM / 2 / 16;                 // activation sub-tiles per wave
+  constexpr int WTN = BN / 4, WTM = BM / 2;
   constexpr int A_BYTES = PBM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_LOADS = 2;                      // 16 pieces of 16 rows over 8 waves
-  constexpr int B_PIECES = BN / 16;               // 16 or 20
+  // 1-KiB DMA pieces (16 rows x 64 B) are dealt to waves as piece = j*8 + wave; when the count is not a
+  // multiple of 8 it is 4 mod 8, so waves 0-3 ("early" half) issue one piece more than waves 4-7.
+  constexpr int A_PIECES = BM / 16, B_PIECES = BN / 16;
+  constexpr int A_LOADS = (A_PIECES + 7) / 8, A_LOADS_HI = A_PIECES / 8;
+  constexpr int A_SPLIT = A_PIECES % 8 == 0 ? 8 : A_PIECES % 8;
   constexpr int B_LOADS_LO = (B_PIECES + 7) / 8;  // waves 0..(B_PIECES%8 - 1) (all waves if divisible)
   constexpr int B_LOADS_HI = B_PIECES / 8;        // the other waves
   constexpr int B_SPLIT = B_PIECES % 8 == 0 ? 8 : B_PIECES % 8;   // waves below this index take B_LOADS_LO
-  static_assert(B_SPLIT == 8 || B_SPLIT == 4, "wave halves must have uniform DMA counts");
+  static_assert((B_SPLIT == 8 || B_SPLIT == 4) && (A_SPLIT == 8 || A_SPLIT == 4), "wave halves must have uniform DMA counts");
   constexpr int L_EARLY = A_LOADS + B_LOADS_LO;   // waves 0-3
-  constexpr int L_LATE = A_LOADS + (B_SPLIT == 8 ? B_LOADS_LO : B_LOADS_HI);   // waves 4-7
+  constexpr int L_LATE = (A_SPLIT == 8 ? A_LOADS : A_LOADS_HI) + (B_SPLIT == 8 ? B_LOADS_LO : B_LOADS_HI);   // waves 4-7
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -55,7 +63,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
   const int wm = wave >> 2, wn = wave & 3;
   const bool late = wave >= 4;
 
-  constexpr int GM = 4;
+  constexpr int GM = BM == 128 ? 8 : 4;
   const int nwg = p.tiles_m * p.tiles_n;
   const int t = xcd_remap(blockIdx.x, nwg);
   const int per_group = GM * p.tiles_n;
@@ -75,9 +83,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
   int schunk_a[A_LOADS];
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) {
-    const int r = (wave * A_LOADS + i) * 16 + lrow;
+    const int r = (i * 8 + wave) * 16 + lrow;
     const int m = tile_m * PBM + r;
-    a_in[i] = m < p.m;
+    a_in[i] = m < p.m && r < PBM;
     schunk_a[i] = (lchunk ^ swz4(r)) * 8;
     if (p.mode == SP_A_CONV3X3) {
       const int per_img = p.hout * p.wout;
@@ -141,8 +149,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
     char *sb = sa + A_BYTES;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-      glds16(aptr[i], sa + (wave * A_LOADS + i) * 1024);
-      aptr[i] += astep[i];
+      if (i < A_LOADS_HI || wave < A_SPLIT) {     // wave-uniform
+        glds16(aptr[i], sa + (i * 8 + wave) * 1024);
+        aptr[i] += astep[i];
+      }
     }
 #pragma unroll
     for (int j = 0; j < B_LOADS_LO; ++j) {
@@ -169,10 +179,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
 #pragma unroll
   for (int j = 0; j < TM; ++j) offa[j] = (wm * WTM + j * 16 + fr) * 64 + rd_chunk;
 
-  int staged = 0, in_tap = 0, tap = 0;
+  int staged = 0, in_tap = 0, tap = 0, stage_slot = 0, read_slot = 0;
   auto stage_next = [&]() {
     if (in_tap == cpt) { ++tap; in_tap = 0; set_tap(tap); }
-    stage(staged & (PSTAGES - 1));
+    stage(stage_slot);
+    stage_slot = stage_slot + 1 == PSTAGES ? 0 : stage_slot + 1;
     ++staged; ++in_tap;
   };
   set_tap(0);
@@ -193,7 +204,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
     // queue behind the CU's single 64 B/clk texture-address path (about 100 cycles each when four waves issue
     // together); placed after the ds_reads they stall a wave that has nothing left to issue anyway.
     const bool issue = kt + PDIST < nk;
-    const char *sa = smem + (kt & (PSTAGES - 1)) * STAGE;
+    const char *sa = smem + read_slot * STAGE;
+    read_slot = read_slot + 1 == PSTAGES ? 0 : read_slot + 1;
     const char *sb = sa + A_BYTES;
     f16x8 fw[TN], fa[TM];
     if (!(dbg & 64) || kt == 0) {  // (dbg is constexpr)
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
   }
   if (!late) __builtin_amdgcn_s_barrier();
 
-  // ---------------------------------------------------------------- epilogue (two 128-row halves)
+  // ---------------------------------------------------------------- epilogue (two halves of WTM rows)
   const int bno = p.geglu ? BN / 2 : BN;
   const int ldc = bno + 8;
   f16 *sc = (f16 *)smem;
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
             const int ml = j * 16 + fr;                      // row within the half
             f32x4 v = acc[i][j] + b;
             if (p.bias2) {
-              const int64_t m = (int64_t)tile_m * PBM + half * 128 + ml;
+              const int64_t m = (int64_t)tile_m * PBM + half * WTM + ml;
               const int64_t brow = m < p.m ? m / p.bias2_rows : 0;
               v += *(const f32x4 *)(p.bias2 + brow * p.ldb2 + n);
             }
@@ -297,9 +309,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
       }
     }
     __syncthreads();
-    for (int idx = tid; idx < 128 * cpr; idx += 512) {
+    for (int idx = tid; idx < WTM * cpr; idx += 512) {
       const int r = idx / cpr, c = idx - r * cpr;
-      const int64_t m = (int64_t)tile_m * PBM + half * 128 + r;
+      const int64_t m = (int64_t)tile_m * PBM + half * WTM + r;
       if (m >= p.m) continue;
       const int col = tile_n * bno + c * 8;
       if (col >= nstore) continue;
@@ -331,38 +343,45 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
   }
 }
 
-template <int BN, int EXP = 0>
+template <int BM, int BN, int EXP = 0>
 int launch_pp(GemmArgs &a, hipStream_t s) {
-  constexpr size_t lds = (size_t)PSTAGES * (PBM + BN) * 64;
-  static_assert((size_t)128 * (BN + 8) * 2 <= lds, "half-tile staging must fit in the ring");
+  constexpr int NSTG = BM == 128 ? 3 : 4;
+  constexpr size_t lds = (size_t)NSTG * (BM + BN) * 64;
+  static_assert((size_t)(BM / 2) * (BN + 8) * 2 <= lds, "half-tile staging must fit in the ring");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)gemm_pp_kernel<BN, EXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)gemm_pp_kernel<BM, BN, EXP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
     attr_set = true;
   }
-  a.tiles_m = (a.m + PBM - 1) / PBM;
+  a.tiles_m = (a.m + BM - 1) / BM;
   a.tiles_n = a.n / BN;
   SP_CLEAR_STALE_ERROR();
-  hipLaunchKernelGGL((gemm_pp_kernel<BN, EXP>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, EXP>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
   SP_CHECK_LAUNCH("sp_gemm_f16(pp)");
   return SP_OK;
 }
 
 }  // namespace
 
-int launch_pp256(GemmArgs &a, hipStream_t s) {
+int launch_pp(GemmArgs &a, int bm, int bn, hipStream_t s) {
 #ifdef SP_GEMM_EXPERIMENTS
-  switch (a.dbg) {
-    case 1: return launch_pp<256, 1>(a, s);
-    case 2: return launch_pp<256, 2>(a, s);
-    case 3: return launch_pp<256, 3>(a, s);
-    case 65: return launch_pp<256, 65>(a, s);
-    case 67: return launch_pp<256, 67>(a, s);
+  if (bm == 256 && bn == 256) switch (a.dbg) {
+    case 1: return launch_pp<256, 256, 1>(a, s);
+    case 2: return launch_pp<256, 256, 2>(a, s);
+    case 3: return launch_pp<256, 256, 3>(a, s);
+    case 65: return launch_pp<256, 256, 65>(a, s);
+    case 67: return launch_pp<256, 256, 67>(a, s);
     default: break;
   }
 #endif
-  return launch_pp<256>(a, s);
+  if (bn == 256) {
+    if (bm == 128) return launch_pp<128, 256>(a, s);
+    if (bm == 192) return launch_pp<192, 256>(a, s);
+    return launch_pp<256, 256>(a, s);
+  }
+  if (bm == 192) return launch_pp<192, 320>(a, s);
+  return launch_pp<256, 320>(a, s);
 }
-int launch_pp320(GemmArgs &a, hipStream_t s) { return launch_pp<320>(a, s); }
 
 }  // namespace spgemm
