@@ -31,7 +31,18 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
   for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
   const f16 *base = x + ((int64_t)inst * rows) * c + o * 8;
   if (pr < P) {
-    for (int64_t r = r0 + pr; r < r1; r += P) {
+    // four independent 16-byte loads in flight per thread (memory-level parallelism), then accumulate
+    int64_t r = r0 + pr;
+    for (; r + 3 * (int64_t)P < r1; r += 4 * (int64_t)P) {
+      f16x8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const f16x8 *)(base + (r + (int64_t)u * P) * c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e]; s[e] += f; ss[e] += f * f; }
+    }
+    for (; r < r1; r += P) {
       const f16x8 v = *(const f16x8 *)(base + r * c);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; ss[e] += f * f; }
@@ -57,20 +68,25 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
 }
 
 // one block per instance: fold the per-split partials into mean / rstd (fixed order, fp64)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ part,
-                                                          float *__restrict__ stats, int64_t rows, int c,
-                                                          int groups, int splits, float eps) {
-  __shared__ double sh[256 * 2];
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float *__restrict__ part,
+                                                           float *__restrict__ stats, int64_t rows, int c,
+                                                           int groups, int splits, float eps) {
+  __shared__ double sh[1024 * 2];
   const int tid = threadIdx.x, inst = blockIdx.x;
-  const int slices = 256 / groups;
+  const int slices = 1024 / groups;
   const int g = tid % groups, sl = tid / groups;
   double a = 0.0, b = 0.0;
   if (sl < slices) {
-    const float *src = part + ((int64_t)inst * splits * groups + g) * 2;
-    for (int sp = sl; sp < splits; sp += slices) {
-      a += src[(int64_t)sp * groups * 2];
-      b += src[(int64_t)sp * groups * 2 + 1];
+    const float2 *src = (const float2 *)(part + ((int64_t)inst * splits * groups + g) * 2);
+    int sp = sl;
+    for (; sp + 3 * slices < splits; sp += 4 * slices) {       // four loads in flight
+      float2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = src[(int64_t)(sp + u * slices) * groups];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a += v[u].x; b += v[u].y; }
     }
+    for (; sp < splits; sp += slices) { const float2 v = src[(int64_t)sp * groups]; a += v.x; b += v.y; }
   }
   sh[tid * 2] = a; sh[tid * 2 + 1] = b;
   __syncthreads();
@@ -110,7 +126,24 @@ __global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restri
   int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
   const f16 *xb = x + ((int64_t)inst * rows) * c + o * 8;
   f16 *yb = y + ((int64_t)inst * rows) * c + o * 8;
-  for (int64_t r = r0 + pr; r < r1; r += P) {
+  int64_t r = r0 + pr;
+  for (; r + 3 * (int64_t)P < r1; r += 4 * (int64_t)P) {     // four loads in flight per thread
+    f16x8 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const f16x8 *)(xb + (r + (int64_t)u * P) * c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      f16x8 w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)v[u][e] * sc[e] + sf[e];
+        if (silu) f = silu_f(f);
+        w[e] = (f16)f;
+      }
+      *(f16x8 *)(yb + (r + (int64_t)u * P) * c) = w;
+    }
+  }
+  for (; r < r1; r += P) {
     const f16x8 v = *(const f16x8 *)(xb + r * c);
     f16x8 w;
 #pragma unroll
@@ -124,8 +157,8 @@ __global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restri
 }
 
 int gn_splits(int instances, int64_t rows, int P) {
-  int64_t want = (2048 + instances - 1) / instances;
-  int64_t maxs = rows / (4 * (int64_t)P); if (maxs < 1) maxs = 1;
+  int64_t want = (1024 + instances - 1) / instances;
+  int64_t maxs = rows / (16 * (int64_t)P); if (maxs < 1) maxs = 1;   // >= 16 row-iterations per thread
   if (want > maxs) want = maxs;
   if (want > 512) want = 512;
   if (want < 1) want = 1;
@@ -218,14 +251,14 @@ extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *
                      (float *)ws, rows, c, groups, splits);
   SP_CHECK_LAUNCH("sp_groupnorm_f16(stats)");
   int64_t blocks_y = (2048 + instances - 1) / instances;
-  int64_t maxb = (rows + 4 * P - 1) / (4 * P);
+  int64_t maxb = (rows + 16 * P - 1) / (16 * P);
   if (blocks_y > maxb) blocks_y = maxb;
   if (blocks_y < 1) blocks_y = 1;
   const int64_t rpb = (rows + blocks_y - 1) / blocks_y;
   blocks_y = (rows + rpb - 1) / rpb;
   SP_CLEAR_STALE_ERROR();
   float *stats = (float *)ws + (size_t)instances * splits * groups * 2;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(instances), dim3(256), 0, s, (const float *)ws, stats, rows, c,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(instances), dim3(1024), 0, s, (const float *)ws, stats, rows, c,
                      groups, splits, eps);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(instances, (unsigned)blocks_y), dim3(threads), 0, s,
                      (const f16 *)x, (const float *)stats, gamma, beta, (f16 *)y, rows, c, groups, fuse_silu,
