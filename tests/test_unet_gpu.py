@@ -29,7 +29,7 @@ def _build(c=64, seed=3):
     return cfg, sd, ref, SVDUNetHIP(cfg, sd, DEV)
 
 
-@pytest.mark.parametrize("frames,h,w", [(3, 16, 24), (14, 8, 16)])
+@pytest.mark.parametrize("frames,h,w", [(3, 16, 24), (14, 8, 16), (25, 8, 8)])
 def test_unet_forward_matches_oracle(frames, h, w):
     cfg, sd, ref, hip = _build()
     g = torch.Generator().manual_seed(11)
@@ -105,3 +105,48 @@ def test_step_arithmetic_matches_reference_golden(golden_dir):
             ops.euler_step(x, eps_c, eps_u, gvec, new, ld_eps=4, sigma=sigma, sigma_next=sigma_next, b=b, frames=f, h=h, w=w)
             err = rel_l2(new.float(), want)
             assert err <= 2e-3, f"{gs_name} step {step}: rel_l2={err:.3e}"
+
+
+def test_adapter_errors_and_api_surface():
+    """Same error behaviour as the reference adapter (svd_unet.py:367-375) and the same public attributes."""
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+
+    cfg, sd, ref, hip = _build(seed=9)
+    model = StableVideoUNet(unet=hip, timesteps=StableVideoUNet._default_timestep_schedule(25))
+    lat = torch.zeros(1, 4, 2, 8, 8, dtype=torch.float16, device=DEV)
+    with pytest.raises(RuntimeError):
+        model(lat, 0)                                   # conditioning not set
+    model.set_dummy_conditioning(1, 2, 8, 8, torch.device(DEV))
+    for bad in (-1, 25, 100):
+        with pytest.raises(ValueError):
+            model(lat, bad)
+    out = model(lat, 24)                                # last step: sigma_next == 0
+    assert out.shape == lat.shape and out.dtype == torch.float16 and torch.isfinite(out).all()
+    assert abs(model.init_noise_sigma - (700.0 ** 2 + 1) ** 0.5) < 1e-3
+    assert len(model.sigmas) == 26 and float(model.sigmas[-1]) == 0.0
+    assert model._added_time_ids.tolist() == [[5.0, 127.0, torch.tensor(0.02).half().item()]]
+    model.clear_conditioning()
+    with pytest.raises(RuntimeError):
+        model(lat, 0)
+    with pytest.raises(ValueError):
+        StableVideoUNet.from_pretrained("stabilityai/stable-video-diffusion-img2vid-xt")   # hub id: no network
+
+
+def test_pipeline_stage_on_gpu_single_rank_matches_loop():
+    """PipelineStage (world_size 1) driving the HIP adapter == calling the adapter in a loop (bit-identical)."""
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+    from vdpp_amd.pipeline import LatentSpec, run_single_latent
+
+    cfg, sd, ref, hip = _build(seed=13)
+    steps = 5
+    model = StableVideoUNet(unet=hip, timesteps=StableVideoUNet._default_timestep_schedule(steps))
+    torch.manual_seed(3)
+    model.set_dummy_conditioning(1, 3, 8, 8, torch.device(DEV))
+    lat = (torch.randn(1, 4, 3, 8, 8) * model.init_noise_sigma).half().to(DEV)
+    spec = LatentSpec(shape=lat.shape, dtype=torch.float16, device=torch.device(DEV))
+    out = run_single_latent(model, total_steps=steps, timesteps=list(range(steps)), world_size=1, rank=0,
+                            latent_spec=spec, input_latent=lat)
+    want = lat
+    for s in range(steps):
+        want = model(want, s)
+    assert torch.equal(out, want)
