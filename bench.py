@@ -249,9 +249,17 @@ def main():
             acc = by.setdefault(kind, [0.0, 0.0, 0])
             acc[0] += fl; acc[1] += e0.elapsed_time(e1) / 1e3; acc[2] += 1
         gf, gt, gn = by["gemm"]
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_f16_kernel (implicit-GEMM conv/linear)",
+        traffic, traffic_src = None, None
+        try:  # PMC-derived bytes per launch are collected off-line (tools/pmc_forward.sh) and committed
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = (pj["fabric_read_bytes"] + pj["write_bytes"]) / pj["launches"]
+            traffic_src = pj["source"]
+        except Exception:
+            pass
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_f16_kernel (implicit-GEMM conv/linear)",
                            "achieved": gf / gt / 1e12, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": gf / gt / 1e12 / PEAK_FP16_TFLOPS, "traffic": None,
+                           "frac": gf / gt / 1e12 / PEAK_FP16_TFLOPS, "traffic": traffic,
+                           "traffic_source": traffic_src,
                            "launches_per_forward": gn, "avg_launch_us": 1e6 * gt / gn,
                            "flop_per_launch_avg": gf / gn}
         if "attn_spatial" in by:
