@@ -150,3 +150,23 @@ def test_pipeline_stage_on_gpu_single_rank_matches_loop():
     for s in range(steps):
         want = model(want, s)
     assert torch.equal(out, want)
+
+
+def test_batched_cfg_equals_sequential_cfg():
+    """Batch-2 CFG forward (extension) vs the reference's two sequential passes: same kernels on the same rows,
+    only GEMM tile scheduling differs -> bit-identical or within fp16 round-off (1e-3 relative L2)."""
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+
+    cfg, sd, ref, hip = _build(seed=17)
+    ts = StableVideoUNet._default_timestep_schedule(25)
+    seq = StableVideoUNet(unet=hip, timesteps=ts)
+    bat = StableVideoUNet(unet=hip, timesteps=ts, batched_cfg=True)
+    g = torch.Generator().manual_seed(5)
+    frames, h, w = 4, 8, 16
+    emb = torch.randn(1, 1, cfg.cross_attention_dim, generator=g).half().to(DEV)
+    img = torch.randn(1, 4, frames, h, w, generator=g).half().to(DEV)
+    for m in (seq, bat):
+        m.set_conditioning(emb, img, guidance_scale=3.0, num_frames=frames)
+    lat = (torch.randn(1, 4, frames, h, w, generator=g) * 50).half().to(DEV)
+    a, b = seq(lat, 7), bat(lat, 7)
+    assert rel_l2(b.float(), a.float().cpu()) <= 1e-3

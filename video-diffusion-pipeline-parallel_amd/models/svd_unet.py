@@ -36,8 +36,13 @@ class StableVideoUNet(nn.Module):
         timesteps: Sequence[int],
         dtype: torch.dtype = torch.float16,
         num_train_timesteps: int = 1000,
+        batched_cfg: bool = False,
     ) -> None:
+        """``batched_cfg`` (extension): run the unconditional and conditional passes of
+        classifier-free guidance as ONE batch-2 UNet forward instead of two sequential passes
+        (ref ``svd_unet.py:384-411`` runs them one after the other)."""
         super().__init__()
+        self.batched_cfg = batched_cfg
         if dtype != torch.float16:
             raise ValueError("the MI355X SVD path computes in float16 (fp32 accumulate)")
         if not isinstance(unet, SVDUNetHIP):
@@ -218,9 +223,17 @@ class StableVideoUNet(nn.Module):
         in_scale = 1.0 / math.sqrt(sigma * sigma + 1.0)
 
         eps_u = None
-        if self._guidance_scale is not None and self._guidance_scale > 1.0:
-            eps_u = self._unet_pass(latent, self._uncond_image_latents, self._uncond_embeddings, in_scale, step)
-        eps_c = self._unet_pass(latent, self._image_latents, self._image_embeddings, in_scale, step)
+        guided = self._guidance_scale is not None and self._guidance_scale > 1.0
+        if guided and self.batched_cfg:
+            both = self._unet_pass(torch.cat([latent, latent], dim=0),
+                                   torch.cat([self._uncond_image_latents, self._image_latents], dim=0),
+                                   torch.cat([self._uncond_embeddings, self._image_embeddings], dim=0), in_scale, step)
+            half = both.shape[0] // 2
+            eps_u, eps_c = both[:half], both[half:]
+        else:
+            if guided:
+                eps_u = self._unet_pass(latent, self._uncond_image_latents, self._uncond_embeddings, in_scale, step)
+            eps_c = self._unet_pass(latent, self._image_latents, self._image_embeddings, in_scale, step)
         out = torch.empty_like(latent)
         ops.euler_step(latent, eps_c, eps_u, self._guidance32 if eps_u is not None else None, out,
                        ld_eps=eps_c.shape[1], sigma=sigma, sigma_next=sigma_next, b=b, frames=f, h=h, w=w)
