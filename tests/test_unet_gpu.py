@@ -170,3 +170,28 @@ def test_batched_cfg_equals_sequential_cfg():
     lat = (torch.randn(1, 4, frames, h, w, generator=g) * 50).half().to(DEV)
     a, b = seq(lat, 7), bat(lat, 7)
     assert rel_l2(b.float(), a.float().cpu()) <= 1e-3
+
+
+def test_graph_replay_equals_eager():
+    """HIP-graph replay of a step (capture once, replay with new latents) is bit-identical to eager launches."""
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+
+    cfg, sd, ref, hip = _build(seed=19)
+    ts = StableVideoUNet._default_timestep_schedule(25)
+    eager = StableVideoUNet(unet=hip, timesteps=ts)
+    graphed = StableVideoUNet(unet=hip, timesteps=ts)
+    graphed.enable_graphs()
+    g = torch.Generator().manual_seed(6)
+    frames, h, w = 3, 8, 16
+    emb = torch.randn(1, 1, cfg.cross_attention_dim, generator=g).half().to(DEV)
+    img = torch.randn(1, 4, frames, h, w, generator=g).half().to(DEV)
+    for m in (eager, graphed):
+        m.set_conditioning(emb, img, num_frames=frames)
+    for trial in range(3):                       # first call captures, later calls replay with different data
+        lat = (torch.randn(1, 4, frames, h, w, generator=g) * 100).half().to(DEV)
+        for step in (0, 3):
+            a, b = eager(lat, step), graphed(lat, step)
+            assert torch.equal(a, b), f"trial {trial} step {step}"
+    assert len(graphed._graphs) == 2
+    graphed.set_conditioning(emb * 2, img, num_frames=frames)     # invalidates the captured graphs
+    assert len(graphed._graphs) == 0

@@ -43,6 +43,9 @@ class StableVideoUNet(nn.Module):
         (ref ``svd_unet.py:384-411`` runs them one after the other)."""
         super().__init__()
         self.batched_cfg = batched_cfg
+        self._use_graphs = os.environ.get("VDPP_GRAPHS", "0") == "1"
+        self._graphs: dict = {}
+        self._graph_pool = None
         if dtype != torch.float16:
             raise ValueError("the MI355X SVD path computes in float16 (fp32 accumulate)")
         if not isinstance(unet, SVDUNetHIP):
@@ -126,6 +129,16 @@ class StableVideoUNet(nn.Module):
         del sd
         return cls(unet=unet, timesteps=timesteps)
 
+    def enable_graphs(self, enabled: bool = True) -> None:
+        """Replay each diffusion step from a captured HIP graph (one graph per step index and latent shape).
+
+        A step is ~1,100 kernel launches issued from Python; the graph removes that host work from the critical path
+        (it matters when the host is slow or the latent is small; at the benchmark shape the GPU is the bottleneck
+        either way).  Graphs share one memory pool; conditioning changes invalidate them."""
+        self._use_graphs = enabled
+        if not enabled:
+            self._graphs.clear()
+
     def enable_memory_optimizations(self) -> None:
         """Kept for API compatibility (ref ``svd_unet.py:166-194``); nothing to toggle here."""
 
@@ -153,6 +166,7 @@ class StableVideoUNet(nn.Module):
         self._image_embeddings = image_embeddings.to(dev, self.dtype).contiguous()
         self._image_latents = image_latents.to(dev, self.dtype).contiguous()
         self._conditioning_set = True
+        self._graphs.clear()          # captured graphs hold pointers to the previous conditioning tensors
         self._guidance_scale = guidance_scale
         if guidance_scale is not None and guidance_scale > 1.0:
             self._uncond_embeddings = torch.zeros_like(self._image_embeddings)
@@ -218,6 +232,31 @@ class StableVideoUNet(nn.Module):
         if latent.dtype != torch.float16 or not latent.is_cuda:
             raise ValueError("latent must be a float16 tensor on the HIP device")
         latent = latent.contiguous()
+        if self._use_graphs:
+            return self._forward_graph(latent, step)
+        return self._forward_eager(latent, step)
+
+    def _forward_graph(self, latent: torch.Tensor, step: int) -> torch.Tensor:
+        key = (step, tuple(latent.shape))
+        entry = self._graphs.get(key)
+        if entry is None:
+            self._forward_eager(latent, step)             # warm-up: lazy allocations, function attributes
+            torch.cuda.synchronize(latent.device)
+            static_in = latent.clone()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, pool=self._graph_pool):
+                static_out = self._forward_eager(static_in, step)
+            if self._graph_pool is None:
+                self._graph_pool = graph.pool()
+            entry = self._graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = entry
+        static_in.copy_(latent)
+        graph.replay()
+        return static_out.clone()                          # the static buffer is overwritten by the next replay
+
+    def _forward_eager(self, latent: torch.Tensor, step: int) -> torch.Tensor:
+        from ..hip import ops
+
         b, _, f, h, w = latent.shape
         sigma, sigma_next = self._sigma_host[step], self._sigma_host[step + 1]
         in_scale = 1.0 / math.sqrt(sigma * sigma + 1.0)
