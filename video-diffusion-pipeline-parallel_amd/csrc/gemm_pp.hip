@@ -15,6 +15,7 @@
 // S = {0,2,3,1}: makes the ds_read_b128 of a 16x16x32 operand (16 rows x one chunk per 16-lane group)
 // bank-conflict free; applied on the DMA *source* address, undone in the read address.
 #include "gemm_args.h"
+#include <stdlib.h>
 
 namespace spgemm {
 namespace {
@@ -32,6 +33,101 @@ __device__ __forceinline__ void wait_dma(int ksteps_left) {
   if (ksteps_left >= 2) wait_vm<2 * L>();
   else if (ksteps_left == 1) wait_vm<L>();
   else wait_vm<0>();
+}
+
+// Shared epilogue of the ping-pong kernels: bias / time-embedding row / GEGLU in registers, tile staged through the
+// (now idle) LDS ring in two halves of WTM rows, 16-byte coalesced stores with up to two residuals added in fp32.
+template <int PBM, int BN, int TN, int TM, int WTN, int WTM>
+__device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][TM], char *smem, int tile_m,
+                                            int tile_n, int wm, int wn, int tid, int fr, int fq) {
+  const int bno = p.geglu ? BN / 2 : BN;
+  const int ldc = bno + 8;
+  f16 *sc = (f16 *)smem;
+  const int cpr = bno >> 3;
+  const int ncols_total = p.geglu ? p.n / 2 : p.n;
+  const int nstore = p.n_store > 0 ? p.n_store : ncols_total;
+
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+      if (!p.geglu) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int nl = wn * WTN + i * 16 + 4 * fq;
+          const int n = tile_n * BN + nl;
+          f32x4 b = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias) b = *(const f32x4 *)(p.bias + n);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            const int ml = j * 16 + fr;                      // row within the half
+            f32x4 v = acc[i][j] + b;
+            if (p.bias2) {
+              const int64_t m = (int64_t)tile_m * PBM + half * WTM + ml;
+              const int64_t brow = m < p.m ? m / p.bias2_rows : 0;
+              v += *(const f32x4 *)(p.bias2 + brow * p.ldb2 + n);
+            }
+            v *= p.oscale;
+            f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            *(f16x4 *)(sc + ml * ldc + nl) = h;
+          }
+        }
+      } else {
+        if constexpr (TN % 2 == 0) {
+#pragma unroll
+          for (int i = 0; i < TN; i += 2) {
+            const int nl = wn * WTN + i * 16 + 4 * fq;
+            const int n = tile_n * BN + nl;
+            f32x4 bh = {0.f, 0.f, 0.f, 0.f}, bg = bh;
+            if (p.bias) {
+              bh = *(const f32x4 *)(p.bias + n);
+              bg = *(const f32x4 *)(p.bias + n + 16);
+            }
+            const int ol = (wn * WTN + i * 16) / 2 + 4 * fq;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+              const int ml = j * 16 + fr;
+              const f32x4 hv = acc[i][j] + bh, gv = acc[i + 1][j] + bg;
+              f16x4 h;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) h[r] = (f16)(p.oscale * hv[r] * gelu_f(gv[r]));
+              *(f16x4 *)(sc + ml * ldc + ol) = h;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < WTM * cpr; idx += 512) {
+      const int r = idx / cpr, c = idx - r * cpr;
+      const int64_t m = (int64_t)tile_m * PBM + half * WTM + r;
+      if (m >= p.m) continue;
+      const int col = tile_n * bno + c * 8;
+      if (col >= nstore) continue;
+      f16x8 v = *(const f16x8 *)(sc + r * ldc + c * 8);
+      if (p.res1 || p.res2) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+        if (p.res1) {
+          const f16x8 q = *(const f16x8 *)(p.res1 + m * p.ldr1 + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += p.r1scale * (float)q[e];
+        }
+        if (p.res2) {
+          const f16x8 q = *(const f16x8 *)(p.res2 + m * p.ldr2 + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += p.r2scale * (float)q[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (f16)f[e];
+      }
+      if (col + 8 <= nstore) {
+        *(f16x8 *)(p.d + m * p.ldd + col) = v;
+      } else {
+        for (int e = 0; e < nstore - col; ++e) p.d[m * p.ldd + col + e] = v[e];
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // BM = 256: one workgroup per CU (4-deep ring).  BM = 192: same, for row counts where 256-row tiles leave a
@@ -252,95 +348,7 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
   }
   if (!late) __builtin_amdgcn_s_barrier();
 
-  // ---------------------------------------------------------------- epilogue (two halves of WTM rows)
-  const int bno = p.geglu ? BN / 2 : BN;
-  const int ldc = bno + 8;
-  f16 *sc = (f16 *)smem;
-  const int cpr = bno >> 3;
-  const int ncols_total = p.geglu ? p.n / 2 : p.n;
-  const int nstore = p.n_store > 0 ? p.n_store : ncols_total;
-
-  for (int half = 0; half < 2; ++half) {
-    if (wm == half) {
-      if (!p.geglu) {
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          const int nl = wn * WTN + i * 16 + 4 * fq;
-          const int n = tile_n * BN + nl;
-          f32x4 b = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias) b = *(const f32x4 *)(p.bias + n);
-#pragma unroll
-          for (int j = 0; j < TM; ++j) {
-            const int ml = j * 16 + fr;                      // row within the half
-            f32x4 v = acc[i][j] + b;
-            if (p.bias2) {
-              const int64_t m = (int64_t)tile_m * PBM + half * WTM + ml;
-              const int64_t brow = m < p.m ? m / p.bias2_rows : 0;
-              v += *(const f32x4 *)(p.bias2 + brow * p.ldb2 + n);
-            }
-            v *= p.oscale;
-            f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-            *(f16x4 *)(sc + ml * ldc + nl) = h;
-          }
-        }
-      } else {
-        if constexpr (TN % 2 == 0) {
-#pragma unroll
-          for (int i = 0; i < TN; i += 2) {
-            const int nl = wn * WTN + i * 16 + 4 * fq;
-            const int n = tile_n * BN + nl;
-            f32x4 bh = {0.f, 0.f, 0.f, 0.f}, bg = bh;
-            if (p.bias) {
-              bh = *(const f32x4 *)(p.bias + n);
-              bg = *(const f32x4 *)(p.bias + n + 16);
-            }
-            const int ol = (wn * WTN + i * 16) / 2 + 4 * fq;
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-              const int ml = j * 16 + fr;
-              const f32x4 hv = acc[i][j] + bh, gv = acc[i + 1][j] + bg;
-              f16x4 h;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) h[r] = (f16)(p.oscale * hv[r] * gelu_f(gv[r]));
-              *(f16x4 *)(sc + ml * ldc + ol) = h;
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < WTM * cpr; idx += 512) {
-      const int r = idx / cpr, c = idx - r * cpr;
-      const int64_t m = (int64_t)tile_m * PBM + half * WTM + r;
-      if (m >= p.m) continue;
-      const int col = tile_n * bno + c * 8;
-      if (col >= nstore) continue;
-      f16x8 v = *(const f16x8 *)(sc + r * ldc + c * 8);
-      if (p.res1 || p.res2) {
-        float f[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
-        if (p.res1) {
-          const f16x8 q = *(const f16x8 *)(p.res1 + m * p.ldr1 + col);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] += p.r1scale * (float)q[e];
-        }
-        if (p.res2) {
-          const f16x8 q = *(const f16x8 *)(p.res2 + m * p.ldr2 + col);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] += p.r2scale * (float)q[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (f16)f[e];
-      }
-      if (col + 8 <= nstore) {
-        *(f16x8 *)(p.d + m * p.ldd + col) = v;
-      } else {
-        for (int e = 0; e < nstore - col; ++e) p.d[m * p.ldd + col + e] = v[e];
-      }
-    }
-    __syncthreads();
-  }
+  pp_epilogue<PBM, BN, TN, TM, WTN, WTM>(p, acc, smem, tile_m, tile_n, wm, wn, tid, fr, fq);
 }
 
 template <int BM, int BN, int EXP = 0>
