@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--width", type=int, default=LAT_W)
     ap.add_argument("--total-steps", type=int, default=TOTAL_STEPS)
     ap.add_argument("--guidance-scale", type=float, default=None)
+    ap.add_argument("--concurrent", type=int, default=None,
+                    help="videos kept in flight per GPU on separate HIP streams (1 = the reference's sequential "
+                         "order; default 2 on one GPU, 1 across GPUs where the RCCL path could not be rehearsed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
@@ -129,8 +132,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     n = world
-    steps = args.steps if args.steps is not None else (4 if n == 1 else 4 * n)
-    warmup = args.warmup if args.warmup is not None else (1 if n == 1 else n)
+    conc = max(1, args.concurrent if args.concurrent is not None else (2 if n == 1 else 1))
+    steps = args.steps if args.steps is not None else (2 * conc if n == 1 else max(4 * n, 2 * conc))
+    warmup = args.warmup if args.warmup is not None else (conc if n == 1 else max(n, conc))
 
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
@@ -153,7 +157,8 @@ def main():
     import logging
     quiet = logging.getLogger("bench.quiet"); quiet.setLevel(logging.ERROR)
     stage = PipelineStage(model, PipelineConfig(total_steps=T, world_size=n, rank=rank, timesteps=list(range(T)),
-                                                latent_spec=spec, balanced=True), logger=quiet)
+                                                latent_spec=spec, balanced=True, concurrent_samples=conc),
+                          logger=quiet)
     gen = torch.Generator(device=device)
 
     def supplier(i):
@@ -172,14 +177,14 @@ def main():
             stage.drain()
         fence()
         done_events = []
+
+        def on_done(_idx):   # runs on the finishing sample's stream, right after its last step was enqueued
+            ev = torch.cuda.Event(enable_timing=True); ev.record(); done_events.append(ev)
+
+        stage.sample_done_hook = on_done
         t0 = time.perf_counter()
         start_ev = torch.cuda.Event(enable_timing=True); start_ev.record()
-        stage._more_samples_expected = True
-        for i in range(steps):
-            stage._more_samples_expected = i + 1 < steps
-            stage._process_single_latent(supplier(warmup + i) if rank == 0 else None, sample_idx=i)
-            if rank == n - 1:
-                ev = torch.cuda.Event(enable_timing=True); ev.record(); done_events.append(ev)
+        stage.run_many(steps, input_supplier=(lambda i: supplier(warmup + i)) if rank == 0 else None)
         stage.drain()
         fence()
         elapsed = time.perf_counter() - t0
@@ -193,7 +198,7 @@ def main():
     steady = None
     fill = None
     if rank == n - 1:
-        times = [start_ev.elapsed_time(e) / 1e3 for e in done_events]
+        times = sorted(start_ev.elapsed_time(e) / 1e3 for e in done_events)
         fill = times[0]
         drop = min(n - 1, len(times) - 1) if n > 1 else 0
         if len(times) - drop >= 2:
@@ -218,7 +223,8 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"SVD img2vid UNet (1.52B params, random init), latent (1,4,{args.frames},"
                                    f"{args.height},{args.width}) fp16, {T} steps, {passes} UNet pass/step "
-                                   f"(guidance_scale={args.guidance_scale}), 1 video per pipeline slot",
+                                   f"(guidance_scale={args.guidance_scale}), {conc} videos in flight per GPU "
+                                   f"on separate HIP streams",
                        "stage_steps": stage_sizes(T, n, balanced=True),
                        "parallelism": f"step-pipeline pp{n}" if n > 1 else "single GPU (no pipeline split)"},
             "steady_state_videos_per_s_last_rank": steady, "first_video_latency_s": fill,

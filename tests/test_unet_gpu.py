@@ -195,3 +195,30 @@ def test_graph_replay_equals_eager():
     assert len(graphed._graphs) == 2
     graphed.set_conditioning(emb * 2, img, num_frames=frames)     # invalidates the captured graphs
     assert len(graphed._graphs) == 0
+
+
+def test_interleaved_run_many_equals_sequential():
+    """concurrent_samples > 1 (samples interleaved on separate HIP streams) returns exactly the sequential results."""
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+    from vdpp_amd.pipeline import LatentSpec, PipelineConfig, PipelineStage
+
+    cfg, sd, ref, hip = _build(seed=23)
+    steps = 4
+    model = StableVideoUNet(unet=hip, timesteps=StableVideoUNet._default_timestep_schedule(steps))
+    torch.manual_seed(4)
+    model.set_dummy_conditioning(1, 3, 8, 16, torch.device(DEV))
+    shape = torch.Size((1, 4, 3, 8, 16))
+    spec = LatentSpec(shape=shape, dtype=torch.float16, device=torch.device(DEV))
+    xs = [(torch.randn(shape) * 10 * (i + 1)).half().to(DEV) for i in range(5)]
+    outs = {}
+    for conc in (1, 2, 3):
+        stage = PipelineStage(model, PipelineConfig(total_steps=steps, world_size=1, rank=0, timesteps=list(range(steps)),
+                                                    latent_spec=spec, concurrent_samples=conc))
+        seen = []
+        stage.sample_done_hook = seen.append
+        outs[conc] = stage.run_many(5, input_supplier=lambda i: xs[i])
+        torch.cuda.synchronize()
+        assert sorted(seen) == [0, 1, 2, 3, 4]
+    for conc in (2, 3):
+        for a, b in zip(outs[1], outs[conc]):
+            assert torch.equal(a, b)

@@ -330,8 +330,13 @@ class SVDUNetHIP:
         temb_dim, c0 = cfg.time_embed_dim, cfg.block_out_channels[0]
         max_c = 2 * max(cfg.block_out_channels)
         ws_bytes = ops.groupnorm_ws_bytes(b * frames, frames * h * w, max_c, cfg.norm_groups)
-        if self._gn_ws is None or self._gn_ws.numel() < ws_bytes:
-            self._gn_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        # GroupNorm partial-sum scratch: one per HIP stream, forwards on different streams may overlap in time
+        if self._gn_ws is None:
+            self._gn_ws = {}
+        skey = torch.cuda.current_stream(dev).cuda_stream
+        gn_ws = self._gn_ws.get(skey)
+        if gn_ws is None or gn_ws.numel() < ws_bytes:
+            gn_ws = self._gn_ws[skey] = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
 
         # ---- embeddings (M = 1 GEMVs)
         hid = torch.empty((1, 2 * temb_dim), dtype=torch.float16, device=dev)
@@ -347,7 +352,7 @@ class SVDUNetHIP:
         temb = torch.empty(self.temb_w.shape[0], dtype=torch.float32, device=dev)
         ops.gemv(emb16, self.temb_w, self.temb_b, n=self.temb_w.shape[0], k=temb_dim, y32=temb, silu_in=True)
 
-        r = _Run(b=b, f=frames, h=h, w=w, temb=temb, ctx16=ctx16, gn_ws=self._gn_ws,
+        r = _Run(b=b, f=frames, h=h, w=w, temb=temb, ctx16=ctx16, gn_ws=gn_ws,
                  frame_ids=torch.arange(frames, dtype=torch.float32, device=dev))
 
         geom, _, _ = self._conv_geom(r)
