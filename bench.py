@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--guidance-scale", type=float, default=None)
     ap.add_argument("--concurrent", type=int, default=None,
                     help="videos kept in flight per GPU on separate HIP streams (1 = the reference's sequential "
-                         "order; default 2 on one GPU, 1 across GPUs where the RCCL path could not be rehearsed)")
+                         "order; default 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
@@ -132,7 +132,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     n = world
-    conc = max(1, args.concurrent if args.concurrent is not None else (2 if n == 1 else 1))
+    conc = max(1, args.concurrent if args.concurrent is not None else 2)
     steps = args.steps if args.steps is not None else (2 * conc if n == 1 else max(4 * n, 2 * conc))
     warmup = args.warmup if args.warmup is not None else (conc if n == 1 else max(n, conc))
 

@@ -122,7 +122,9 @@ class _SideStreamLink:
             work.wait()  # stream-level dependency on the RCCL recv
             landed = torch.cuda.Event()
             landed.record(self.stream)
-        torch.cuda.current_stream(self.spec.device).wait_event(landed)
+        consumer = torch.cuda.current_stream(self.spec.device)
+        consumer.wait_event(landed)
+        buf.record_stream(consumer)      # it was allocated on whatever stream posted the receive
         return buf
 
     @property
