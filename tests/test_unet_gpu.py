@@ -222,3 +222,72 @@ def test_interleaved_run_many_equals_sequential():
     for conc in (2, 3):
         for a, b in zip(outs[1], outs[conc]):
             assert torch.equal(a, b)
+
+
+class _FakeWork:
+    def __init__(self, fn=None):
+        self._fn = fn
+
+    def wait(self):
+        if self._fn is not None:
+            self._fn()
+            self._fn = None
+        return True
+
+    def is_completed(self):
+        return True
+
+
+@pytest.mark.parametrize("conc", [1, 2, 3])
+def test_side_stream_link_with_emulated_stream_ordered_p2p(monkeypatch, conc):
+    """Two pipeline ranks emulated in ONE process on one GPU: torch.distributed isend/irecv are replaced by
+    stream-ordered mailbox copies (what RCCL P2P provides: the transfer is ordered after the work already enqueued
+    on the issuing stream).  Exercises _SideStreamLink (events, fresh receive buffers, record_stream) and the
+    interleaved scheduler exactly as the RCCL path does, and checks the 2-rank result == the 1-rank result."""
+    import vdpp_amd.pipeline.pipeline as pl
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+    from vdpp_amd.pipeline import LatentSpec, PipelineConfig, PipelineStage
+
+    mailbox = []          # FIFO of (tensor, ready_event) from rank 0 to rank 1
+
+    def fake_isend(tensor, dst, tag=0):
+        ev = torch.cuda.Event()
+        staged = tensor.clone()                 # on the issuing (side) stream, ordered behind its wait_event
+        ev.record(torch.cuda.current_stream())
+        mailbox.append((staged, ev))
+        return _FakeWork()
+
+    def fake_irecv(buf, src, tag=0):
+        def complete():                          # runs inside work.wait() on the link's side stream
+            staged, ev = mailbox.pop(0)
+            torch.cuda.current_stream().wait_event(ev)
+            buf.copy_(staged)
+        return _FakeWork(complete)
+
+    monkeypatch.setattr(pl.dist, "isend", fake_isend)
+    monkeypatch.setattr(pl.dist, "irecv", fake_irecv)
+
+    cfg, sd, ref, hip = _build(seed=29)
+    steps = 5
+    model = StableVideoUNet(unet=hip, timesteps=StableVideoUNet._default_timestep_schedule(steps))
+    torch.manual_seed(8)
+    model.set_dummy_conditioning(1, 3, 8, 16, torch.device(DEV))
+    shape = torch.Size((1, 4, 3, 8, 16))
+    spec = LatentSpec(shape=shape, dtype=torch.float16, device=torch.device(DEV))
+    xs = [(torch.randn(shape) * 20).half().to(DEV) for _ in range(5)]
+
+    def stage(rank, world):
+        return PipelineStage(model, PipelineConfig(total_steps=steps, world_size=world, rank=rank,
+                                                   timesteps=list(range(steps)), latent_spec=spec, balanced=True,
+                                                   async_comm=world > 1, concurrent_samples=conc))
+
+    want = stage(0, 1).run_many(5, input_supplier=lambda i: xs[i])
+    r0, r1 = stage(0, 2), stage(1, 2)
+    assert (r0.step_range.count, r1.step_range.count) == (3, 2)
+    assert r0.run_many(5, input_supplier=lambda i: xs[i]) is None     # rank 0: everything goes to the mailbox
+    got = r1.run_many(5)
+    r0.drain(); r1.drain()
+    torch.cuda.synchronize()
+    assert not mailbox and len(got) == 5
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
