@@ -200,10 +200,13 @@ def main():
     if rank == n - 1:
         times = sorted(start_ev.elapsed_time(e) / 1e3 for e in done_events)
         fill = times[0]
-        drop = min(n - 1, len(times) - 1) if n > 1 else 0
-        if len(times) - drop >= 2:
-            steady = (len(times) - drop - 1) / (times[-1] - times[drop])
-        elif n == 1:
+        # completions arrive in groups of `conc` (videos interleaved on streams finish together): drop whole groups
+        # covering the pipeline fill (N-1 samples) and rate the rest group-to-group
+        groups_dropped = max(1, -(-(n - 1) // conc))
+        d = groups_dropped * conc
+        if len(times) - d >= 1 and times[-1] > times[d - 1]:
+            steady = (len(times) - d) / (times[-1] - times[d - 1])
+        else:
             steady = len(times) / times[-1]
     info = torch.tensor([steady or 0.0, fill or 0.0], dtype=torch.float64, device=device)
     if n > 1:
