@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--concurrent", type=int, default=None,
                     help="videos kept in flight per GPU on separate HIP streams (1 = the reference's sequential "
                          "order; default 2)")
+    ap.add_argument("--no-rotate", action="store_true",
+                    help="N>1: keep the extra step of the balanced split on the first ranks for every video "
+                         "(default: rotate it with the video index so no stage is a permanent bottleneck)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
@@ -157,7 +160,8 @@ def main():
     import logging
     quiet = logging.getLogger("bench.quiet"); quiet.setLevel(logging.ERROR)
     stage = PipelineStage(model, PipelineConfig(total_steps=T, world_size=n, rank=rank, timesteps=list(range(T)),
-                                                latent_spec=spec, balanced=True, concurrent_samples=conc),
+                                                latent_spec=spec, balanced=True, concurrent_samples=conc,
+                                                rotate=(n > 1 and not args.no_rotate)),
                           logger=quiet)
     gen = torch.Generator(device=device)
 
@@ -229,6 +233,7 @@ def main():
                                    f"(guidance_scale={args.guidance_scale}), {conc} videos in flight per GPU "
                                    f"on separate HIP streams",
                        "stage_steps": stage_sizes(T, n, balanced=True),
+                       "stage_steps_rotate_with_video_index": bool(n > 1 and not args.no_rotate),
                        "parallelism": f"step-pipeline pp{n}" if n > 1 else "single GPU (no pipeline split)"},
             "steady_state_videos_per_s_last_rank": steady, "first_video_latency_s": fill,
             "unet_forward_tflop_algorithmic": flops_all["total"] / 1e12,
@@ -237,7 +242,9 @@ def main():
         # time per UNet forward: at N=1 the whole timed region is forwards; at N>1 the node finishes one video
         # per (bottleneck stage) x (its steps), so this is the per-forward time of the most loaded rank
         per_video = elapsed / steps
-        ms_forward = 1e3 * per_video / (max(stage_sizes(T, n, balanced=True)) * passes)
+        rotating = n > 1 and not args.no_rotate
+        bottleneck_steps = T / n if rotating else max(stage_sizes(T, n, balanced=True))
+        ms_forward = 1e3 * per_video / (bottleneck_steps * passes)
         out["ms_per_unet_forward" if n == 1 else "ms_per_unet_forward_bottleneck_stage"] = ms_forward
         out["step_roofline"] = {"bound": "mfma", "achieved": flops_exec / 1e12 / (ms_forward / 1e3),
                                 "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",

@@ -41,6 +41,40 @@ def test_dummy_unet_shapes_like_reference_tests():
     assert sum(p.numel() for p in DummyUNet(8, 16).parameters()) == 6952
 
 
+def _rot_worker(rank, ws, golden_dir, init_file, out_file):
+    torch.set_num_threads(2)
+    z, model = _load(golden_dir, "dummy_c4h64.npz", 4, 64)
+    init_distributed(backend="gloo", rank=rank, world_size=ws, init_method=f"file://{init_file}")
+    x = torch.from_numpy(z["input"])
+    ts = [6, 5, 4, 3, 2, 1, 0]                                  # 7 steps over 3 ranks: 3,2,2 rotating
+    spec = LatentSpec(shape=x.shape, dtype=torch.float32, device=torch.device("cpu"))
+    quiet = logging.getLogger("quiet"); quiet.setLevel(logging.ERROR)
+    stage = PipelineStage(model, PipelineConfig(total_steps=7, world_size=ws, rank=rank, timesteps=ts, latent_spec=spec,
+                                                balanced=True, rotate=True), logger=quiet)
+    with torch.no_grad():
+        outs = stage.run_many(4, input_supplier=(lambda i: x * (i + 1)) if rank == 0 else None)
+    if rank == ws - 1:
+        torch.save(outs, out_file)
+    finalize_distributed()
+
+
+def test_gloo_rotating_split_world3(golden_dir):
+    """Rotating balanced split (7 steps on 3 ranks) over Gloo == plain loop for every sample, bit-exact."""
+    with tempfile.TemporaryDirectory() as td:
+        out_file = os.path.join(td, "out.pt")
+        mp.spawn(_rot_worker, args=(3, golden_dir, os.path.join(td, "init"), out_file), nprocs=3, join=True)
+        outs = torch.load(out_file)
+    z, model = _load(golden_dir, "dummy_c4h64.npz", 4, 64)
+    x = torch.from_numpy(z["input"])
+    assert len(outs) == 4
+    for i, got in enumerate(outs):
+        lat = x * (i + 1)
+        with torch.no_grad():
+            for s in [6, 5, 4, 3, 2, 1, 0]:
+                lat = model(lat, s)
+        assert torch.equal(got, lat)
+
+
 def _worker(rank, ws, golden_dir, name, c, hid, init_file, out_file, many):
     torch.set_num_threads(2)
     z, model = _load(golden_dir, name, c, hid)

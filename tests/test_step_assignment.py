@@ -4,7 +4,8 @@ count/iteration/validation) expressed as tables, plus the balanced-split extensi
 
 import pytest
 
-from vdpp_amd.pipeline.step_assignment import StepRange, assign_steps, assign_steps_balanced, stage_sizes
+from vdpp_amd.pipeline.step_assignment import (StepRange, assign_steps, assign_steps_balanced,
+                                               assign_steps_rotating, stage_sizes)
 
 KAT_28 = {
     1: [(0, 28)],
@@ -66,3 +67,25 @@ def test_balanced_split_extension():
         assign_steps_balanced(3, 4, 0)
     with pytest.raises(ValueError):
         assign_steps_balanced(25, 8, 8)
+
+
+def test_rotating_split_extension():
+    for total, world in [(25, 8), (25, 4), (25, 2), (30, 8), (28, 7), (9, 4)]:
+        work = [0] * world
+        for sample in range(world):
+            seen = []
+            for r in range(world):
+                rng = assign_steps_rotating(total, world, r, sample)
+                seen.extend(rng)
+                work[r] += rng.count
+                assert rng.count in (total // world, total // world + 1)
+            assert seen == list(range(total))                      # every sample runs all steps, in order
+        assert len(set(work)) == 1 and work[0] == total            # equal work per stage over `world` samples
+    # sample 0 equals the plain balanced split; the heavy stage moves with the sample index
+    assert [assign_steps_rotating(25, 8, r, 0).count for r in range(8)] == stage_sizes(25, 8, balanced=True)
+    assert [assign_steps_rotating(25, 8, r, 3).count for r in range(8)] == [3, 3, 3, 4, 3, 3, 3, 3]
+    assert [assign_steps_rotating(30, 8, r, 7).count for r in range(8)] == [4, 4, 4, 4, 4, 3, 3, 4]
+    with pytest.raises(ValueError):
+        assign_steps_rotating(25, 8, 0, -1)
+    with pytest.raises(ValueError):
+        assign_steps_rotating(3, 4, 0, 0)

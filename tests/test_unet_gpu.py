@@ -238,8 +238,8 @@ class _FakeWork:
         return True
 
 
-@pytest.mark.parametrize("conc", [1, 2, 3])
-def test_side_stream_link_with_emulated_stream_ordered_p2p(monkeypatch, conc):
+@pytest.mark.parametrize("conc,rotate", [(1, False), (2, False), (3, False), (2, True)])
+def test_side_stream_link_with_emulated_stream_ordered_p2p(monkeypatch, conc, rotate):
     """Two pipeline ranks emulated in ONE process on one GPU: torch.distributed isend/irecv are replaced by
     stream-ordered mailbox copies (what RCCL P2P provides: the transfer is ordered after the work already enqueued
     on the issuing stream).  Exercises _SideStreamLink (events, fresh receive buffers, record_stream) and the
@@ -279,7 +279,8 @@ def test_side_stream_link_with_emulated_stream_ordered_p2p(monkeypatch, conc):
     def stage(rank, world):
         return PipelineStage(model, PipelineConfig(total_steps=steps, world_size=world, rank=rank,
                                                    timesteps=list(range(steps)), latent_spec=spec, balanced=True,
-                                                   async_comm=world > 1, concurrent_samples=conc))
+                                                   async_comm=world > 1, concurrent_samples=conc,
+                                                   rotate=rotate and world > 1))
 
     want = stage(0, 1).run_many(5, input_supplier=lambda i: xs[i])
     r0, r1 = stage(0, 2), stage(1, 2)

@@ -8,12 +8,13 @@ from .pipeline import (
     run_pipeline_latents,
     run_single_latent,
 )
-from .step_assignment import StepRange, assign_steps, assign_steps_balanced, stage_sizes
+from .step_assignment import StepRange, assign_steps, assign_steps_balanced, assign_steps_rotating, stage_sizes
 
 __all__ = [
     "StepRange",
     "assign_steps",
     "assign_steps_balanced",
+    "assign_steps_rotating",
     "stage_sizes",
     "LatentSpec",
     "PipelineStage",

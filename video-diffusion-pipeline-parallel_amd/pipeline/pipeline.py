@@ -30,8 +30,9 @@ No collective is involved; one 1-2 MB message per stage boundary per sample trav
 xGMI link between neighbouring ranks.  CPU / Gloo ranks (the simulator path) keep the
 reference's blocking behaviour, which is what the golden vectors in ``tests/golden`` pin.
 
-Extension field (not in the reference): ``PipelineConfig.balanced`` selects
-``assign_steps_balanced`` so 25 steps can be split over 2/4/8 ranks.
+Extension fields (not in the reference): ``PipelineConfig.balanced`` selects ``assign_steps_balanced`` so 25
+steps can be split over 2/4/8 ranks; ``rotate`` additionally rotates the stages that own the extra step with the
+sample index (``assign_steps_rotating``), so no stage is a permanent bottleneck.
 """
 
 from __future__ import annotations
@@ -47,7 +48,7 @@ from typing import Callable, Deque, Optional
 import torch
 import torch.distributed as dist
 
-from .step_assignment import StepRange, assign_steps, assign_steps_balanced
+from .step_assignment import StepRange, assign_steps, assign_steps_balanced, assign_steps_rotating
 
 LOGGER = logging.getLogger(__name__)
 
@@ -76,6 +77,7 @@ class PipelineConfig:
     balanced: bool = False          # use assign_steps_balanced (uneven contiguous split)
     async_comm: Optional[bool] = None  # None = auto (side-stream RCCL when latent is on a GPU)
     concurrent_samples: int = 1     # run_many: samples interleaved on separate HIP streams of this rank
+    rotate: bool = False            # balanced split whose "+1 step" stages rotate with the sample index
 
     def __post_init__(self) -> None:
         if len(self.timesteps) != self.total_steps:
@@ -214,10 +216,19 @@ class PipelineStage:
             dist.send(latent, dst=downstream, tag=self.config.send_tag)
 
     # ------------------------------------------------------------------ compute
-    def _run_local_steps(self, latent: torch.Tensor) -> torch.Tensor:
-        owned = list(self.config.timesteps[self.step_range.start : self.step_range.end])
-        if len(owned) != self.step_range.count:
+    def _owned_timesteps(self, sample_idx: int | None) -> list:
+        """Timesteps this stage runs for one sample (fixed range, or the rotating balanced split)."""
+        cfg = self.config
+        rng = self.step_range
+        if cfg.rotate:
+            rng = assign_steps_rotating(cfg.total_steps, cfg.world_size, cfg.rank, sample_idx or 0)
+        owned = list(cfg.timesteps[rng.start : rng.end])
+        if len(owned) != rng.count:
             raise RuntimeError("Local timestep slice length mismatch with step range.")
+        return owned
+
+    def _run_local_steps(self, latent: torch.Tensor, sample_idx: int | None = None) -> torch.Tensor:
+        owned = self._owned_timesteps(sample_idx)
 
         verbose = self.logger.isEnabledFor(logging.INFO)
         for step in owned:
@@ -276,9 +287,6 @@ class PipelineStage:
         if not hasattr(self, "_streams"):
             self._streams = [torch.cuda.Stream(device=dev) for _ in range(cfg.concurrent_samples)]
         main = torch.cuda.current_stream(dev)
-        owned = list(cfg.timesteps[self.step_range.start : self.step_range.end])
-        if len(owned) != self.step_range.count:
-            raise RuntimeError("Local timestep slice length mismatch with step range.")
         first, last = cfg.rank == 0, cfg.rank == cfg.world_size - 1
         finished: list[torch.Tensor] = []
         for base in range(0, num_samples, cfg.concurrent_samples):
@@ -296,10 +304,12 @@ class PipelineStage:
                     else:
                         self._more_samples_expected = False
                         latents.append(self._recv_latent())
-            for step in owned:
+            owned = [self._owned_timesteps(idx) for idx in group]
+            for k in range(max(len(o) for o in owned)):
                 for j in range(len(group)):
-                    with torch.cuda.stream(self._streams[j]):
-                        latents[j] = self.model(latents[j], step)
+                    if k < len(owned[j]):
+                        with torch.cuda.stream(self._streams[j]):
+                            latents[j] = self.model(latents[j], owned[j][k])
             for j in range(len(group)):
                 with torch.cuda.stream(self._streams[j]):
                     if last:
@@ -331,7 +341,7 @@ class PipelineStage:
             latent = self._recv_latent()
             self._log(f"{label}received latent")
 
-        latent = self._run_local_steps(latent)
+        latent = self._run_local_steps(latent, sample_idx)
 
         if cfg.rank == cfg.world_size - 1:
             self._log(f"{label}final rank completed")

@@ -10,10 +10,12 @@ Mirrors ``/root/reference/src/pipeline/step_assignment.py``:
     ``total_steps <= 0``, ``world_size <= 0``, rank outside ``[0, world_size)``, or
     ``total_steps % world_size != 0``)
 
-Extension (NOT in the reference, separately named so the strict API above is unchanged):
+Extensions (NOT in the reference, separately named so the strict API above is unchanged):
   * ``assign_steps_balanced`` – contiguous split that tolerates a remainder; the first
     ``total_steps % world_size`` ranks take one extra step.  Needed for the 25-step
     schedule on 2/4/8 GPUs that BASELINE.json asks for (25 -> [4,3,3,3,3,3,3,3]).
+  * ``assign_steps_rotating`` – the same split, but the stages that take the extra step rotate with the
+    sample index, which removes the permanent bottleneck stage.
 """
 
 from __future__ import annotations
@@ -82,6 +84,29 @@ def assign_steps_balanced(total_steps: int, world_size: int, rank: int) -> StepR
     per_rank, remainder = divmod(total_steps, world_size)
     first = rank * per_rank + min(rank, remainder)
     return StepRange(start=first, end=first + per_rank + (1 if rank < remainder else 0))
+
+
+def assign_steps_rotating(total_steps: int, world_size: int, rank: int, sample_idx: int) -> StepRange:
+    """Balanced contiguous split whose "+1 step" stages rotate with the sample index (extension).
+
+    With ``R = total_steps % world_size`` the stages ``(sample_idx + k) % world_size`` for ``k < R`` own
+    ``total_steps // world_size + 1`` steps of THAT sample, the others one fewer.  Every sample still runs steps
+    ``0 .. total_steps-1`` in order, but over ``world_size`` consecutive samples each stage does the same amount of
+    work, so the steady-state ceiling of e.g. 25 steps on 8 stages is 8x instead of 25/4 = 6.25x.
+    """
+
+    _validate(total_steps, world_size, rank)
+    if total_steps < world_size:
+        raise ValueError("total_steps must be >= world_size so every rank owns a step.")
+    if sample_idx < 0:
+        raise ValueError("sample_idx must be non-negative.")
+    per_rank, remainder = divmod(total_steps, world_size)
+
+    def extra(r: int) -> int:
+        return 1 if (r - sample_idx) % world_size < remainder else 0
+
+    first = rank * per_rank + sum(extra(r) for r in range(rank))
+    return StepRange(start=first, end=first + per_rank + extra(rank))
 
 
 def stage_sizes(total_steps: int, world_size: int, *, balanced: bool = False) -> list[int]:
