@@ -292,3 +292,33 @@ def test_side_stream_link_with_emulated_stream_ordered_p2p(monkeypatch, conc, ro
     assert not mailbox and len(got) == 5
     for a, b in zip(want, got):
         assert torch.equal(a, b)
+
+
+def test_full_width_svd_unet_matches_oracle():
+    """The REAL SVD architecture (1.52 B parameters, 320/640/1280 channels, 5/10/20 heads) on a small latent
+    (4 frames, 32x32 -> 4,096 token rows at level 0, so the large-tile GEMM kernels run) vs the fp32 oracle.
+    Tolerance: relative L2 <= 2e-2 (fp16 storage through ~1,100 kernels vs fp32 CPU)."""
+    from oracle.svd_unet_ref import SVDUNetConfig, SVDUNetRef
+    from vdpp_amd.models.unet_hip import SVDUNetHIP
+    from vdpp_amd.models.unet_spec import UNetConfig, random_state_dict
+
+    cfg = UNetConfig.svd()
+    sd = random_state_dict(cfg, seed=1, device=DEV, dtype=torch.float16)
+    hip = SVDUNetHIP(cfg, sd, DEV)
+    with torch.device("meta"):
+        ref = SVDUNetRef(SVDUNetConfig.svd())
+    ref = ref.to_empty(device="cpu").eval()
+    ref.load_state_dict({k: v.float().cpu() for k, v in sd.items()}, strict=True)
+    del sd
+    g = torch.Generator().manual_seed(31)
+    frames, h, w = 4, 32, 32
+    sample = torch.randn(1, frames, 8, h, w, generator=g).half()
+    ctx = torch.randn(1, 1, 1024, generator=g).half()
+    ids = torch.tensor([[5.0, 127.0, 0.02]]).half()
+    got = hip(sample.to(DEV), 0.8, ctx.to(DEV), ids.to(DEV))[0]
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want = ref(sample.float(), 0.8, ctx.float(), ids.float())[0]
+    assert torch.isfinite(got).all()
+    err = rel_l2(got.float(), want)
+    assert err <= 2e-2, f"full-width UNet rel_l2={err:.3e}"
