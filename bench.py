@@ -291,8 +291,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.frames, args.height, args.width, T)
         out["cpu_simulator"] = cpu_simulator()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if n > 1:
+        dist.barrier()          # rank 0 ran the roofline leg alone; leave together
         finalize_distributed()
 
 
