@@ -194,7 +194,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_f16_kernel(const GemmArgs
     if (late) __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
       const bool more = kt + 2 < nk;
-      if (more && !(p.dbg & 1)) stage_next();
+      if (more) stage_next();
       const char *sa = smem + (kt % 3) * STAGE;
       const char *sb = sa + A_BYTES;
       f16x8 fw[2][TN], fa[2][TM];
@@ -212,23 +212,13 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_f16_kernel(const GemmArgs
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
-      if (!(p.dbg & 2)) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int i = 0; i < TN; ++i)
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int j = 0; j < TM; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-          for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(fw[ks][i]));
-#pragma unroll
-          for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(fa[ks][j]));
-        }
-      }
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       if (!late) { if (more) wait_vm_lgkm<L>(); else wait_vm_lgkm<0>(); }
       __builtin_amdgcn_sched_barrier(0);
@@ -384,7 +374,9 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   SP_REQUIRE(d->lda >= d->cin && d->lda % 8 == 0, "sp_gemm_f16: lda=%lld invalid", (long long)d->lda);
   SP_REQUIRE(d->ldd % 8 == 0 || d->n_store > 0, "sp_gemm_f16: ldd must be a multiple of 8");
   GemmArgs a{};
-  { const char *e = getenv("SP_GEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
+#ifdef SP_GEMM_EXPERIMENTS
+  { const char *e = getenv("SP_GEMM_DBG"); a.dbg = e ? atoi(e) : 0; }   // ablation builds only (make EXTRA=-DSP_GEMM_EXPERIMENTS)
+#endif
   a.a = (const f16 *)d->a; a.w = (const f16 *)d->w; a.bias = d->bias; a.bias2 = d->bias2;
   a.res1 = (const f16 *)d->res1; a.res2 = (const f16 *)d->res2; a.d = (f16 *)d->d;
   a.zero = (const char *)d->zero_page;

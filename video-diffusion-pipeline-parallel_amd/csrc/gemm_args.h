@@ -28,7 +28,7 @@ struct GemmArgs {
   float oscale, r1scale, r2scale;
   int geglu, n_store;
   int tiles_m, tiles_n;
-  int dbg;   // timing experiments only (SP_GEMM_DBG): 1 = no LDS-DMA in the loop, 2 = no MFMA
+  int dbg;   // ablation builds only (-DSP_GEMM_EXPERIMENTS + SP_GEMM_DBG): selects gemm_pp_kernel<.., EXP>
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
