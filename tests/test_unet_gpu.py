@@ -347,3 +347,37 @@ def test_benchmark_shape_two_kernel_routes_agree_and_are_deterministic(monkeypat
     upd_a, upd_c = (a.float() - lat.float()).cpu(), (c.float() - lat.float()).cpu()
     err = rel_l2(upd_c, upd_a)
     assert err <= 5e-3, f"kernel routes disagree at the benchmark shape: rel_l2={err:.3e}"
+
+
+def test_from_pretrained_local_directory(tmp_path):
+    """from_pretrained on a LOCAL diffusers-style directory (unet/config.json + *.safetensors) builds the same
+    network as handing the state_dict over directly."""
+    import json
+
+    from safetensors.torch import save_file
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+    from vdpp_amd.models.unet_hip import SVDUNetHIP
+    from vdpp_amd.models.unet_spec import UNetConfig, random_state_dict
+
+    cfg = UNetConfig.tiny(64)
+    sd = random_state_dict(cfg, seed=2, dtype=torch.float16)
+    unet_dir = tmp_path / "svd-tiny" / "unet"
+    unet_dir.mkdir(parents=True)
+    save_file(sd, str(unet_dir / "diffusion_pytorch_model.safetensors"))
+    (unet_dir / "config.json").write_text(json.dumps({
+        "_class_name": "UNetSpatioTemporalConditionModel", "in_channels": 8, "out_channels": 4,
+        "block_out_channels": list(cfg.block_out_channels), "layers_per_block": 2,
+        "num_attention_heads": list(cfg.num_attention_heads), "cross_attention_dim": cfg.cross_attention_dim,
+        "addition_time_embed_dim": cfg.addition_time_embed_dim,
+        "projection_class_embeddings_input_dim": cfg.projection_class_embeddings_input_dim,
+        "down_block_types": ["CrossAttnDownBlockSpatioTemporal"] * 3 + ["DownBlockSpatioTemporal"]}))
+    loaded = StableVideoUNet.from_pretrained(str(tmp_path / "svd-tiny"), device=DEV)
+    direct = StableVideoUNet(unet=SVDUNetHIP(cfg, sd, DEV), timesteps=StableVideoUNet._default_timestep_schedule(25))
+    assert len(loaded.timesteps) == 25 and loaded.unet.cfg == cfg
+    g = torch.Generator().manual_seed(1)
+    emb = torch.randn(1, 1, cfg.cross_attention_dim, generator=g).half().to(DEV)
+    img = torch.randn(1, 4, 3, 8, 8, generator=g).half().to(DEV)
+    lat = torch.randn(1, 4, 3, 8, 8, generator=g).half().to(DEV)
+    for m in (loaded, direct):
+        m.set_conditioning(emb, img, num_frames=3)
+    assert torch.equal(loaded(lat, 5), direct(lat, 5))

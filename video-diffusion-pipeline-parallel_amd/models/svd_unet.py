@@ -109,15 +109,41 @@ class StableVideoUNet(nn.Module):
                 f"'{model_id}' is not a local model directory; use StableVideoUNet.from_random_init() for "
                 "synthetic weights (there is no network access to fetch checkpoints)."
             )
+        import json
+
         from safetensors.torch import load_file
 
         sd = {}
         for name in sorted(os.listdir(unet_dir)):
             if name.endswith(".safetensors"):
                 sd.update(load_file(os.path.join(unet_dir, name)))
+        if not sd:
+            raise ValueError(f"no *.safetensors weights under '{unet_dir}'")
+        cfg = UNetConfig.svd()
+        cfg_path = os.path.join(unet_dir, "config.json")
+        if os.path.exists(cfg_path):              # diffusers' UNetSpatioTemporalConditionModel config
+            with open(cfg_path) as fh:
+                raw = json.load(fh)
+            heads = raw.get("num_attention_heads", cfg.num_attention_heads)
+            boc = tuple(raw.get("block_out_channels", cfg.block_out_channels))
+            if isinstance(heads, int):
+                heads = (heads,) * len(boc)
+            down_types = raw.get("down_block_types")
+            cfg = UNetConfig(
+                in_channels=raw.get("in_channels", cfg.in_channels),
+                out_channels=raw.get("out_channels", cfg.out_channels),
+                block_out_channels=boc,
+                layers_per_block=raw.get("layers_per_block", cfg.layers_per_block),
+                num_attention_heads=tuple(heads),
+                cross_attention_dim=raw.get("cross_attention_dim", cfg.cross_attention_dim),
+                addition_time_embed_dim=raw.get("addition_time_embed_dim", cfg.addition_time_embed_dim),
+                projection_class_embeddings_input_dim=raw.get("projection_class_embeddings_input_dim",
+                                                              cfg.projection_class_embeddings_input_dim),
+                down_has_attn=tuple("CrossAttn" in t for t in down_types) if down_types else cfg.down_has_attn,
+            )
         if timesteps is None:
             timesteps = cls._default_timestep_schedule(num_steps=25)
-        return cls(unet=SVDUNetHIP(UNetConfig.svd(), sd, device), timesteps=timesteps, dtype=torch_dtype)
+        return cls(unet=SVDUNetHIP(cfg, sd, device), timesteps=timesteps, dtype=torch_dtype)
 
     @classmethod
     def from_random_init(cls, timesteps: Sequence[int], *, config: UNetConfig | None = None, seed: int = 0,
