@@ -140,6 +140,9 @@ def main():
     steps = args.steps if args.steps is not None else (2 * conc if n == 1 else max(8 * n, 2 * conc))
     warmup = args.warmup if args.warmup is not None else (conc if n == 1 else max(n, conc))
 
+    if os.environ.get("VDPP_SHARE_GPU") == "1":
+        # rehearsal only (PIPELINE_BACKEND=gloo on a one-GPU box): ranks share the cards that exist; RCCL refuses this
+        local_rank %= max(1, torch.cuda.device_count())
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     if n > 1:
