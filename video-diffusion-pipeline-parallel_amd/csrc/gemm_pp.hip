@@ -22,6 +22,20 @@ namespace {
 
 constexpr int PBK = 32, PNW = 8;
 
+
+#ifdef SP_GEMM_EXPERIMENTS
+// per-workgroup phase timestamps (100 MHz wall clock) + hardware id, read back by tools/pp_trace.py
+constexpr int PP_TRACE_WGS = 16384, PP_TRACE_SLOTS = 10;
+__device__ long long g_pp_trace[PP_TRACE_WGS * PP_TRACE_SLOTS];
+#define PP_TRACE(slot)                                                                              \
+  do {                                                                                              \
+    if (threadIdx.x == 0 && blockIdx.x < PP_TRACE_WGS)                                              \
+      g_pp_trace[blockIdx.x * PP_TRACE_SLOTS + (slot)] = wall_clock64();                            \
+  } while (0)
+#else
+#define PP_TRACE(slot) do {} while (0)
+#endif
+
 __device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
 template <int N>
@@ -35,98 +49,122 @@ __device__ __forceinline__ void wait_dma(int ksteps_left) {
   else wait_vm<0>();
 }
 
-// Shared epilogue of the ping-pong kernels: bias / time-embedding row / GEGLU in registers, tile staged through the
-// (now idle) LDS ring in two halves of WTM rows, 16-byte coalesced stores with up to two residuals added in fp32.
-template <int PBM, int BN, int TN, int TM, int WTN, int WTM>
+// Shared epilogue of the ping-pong kernels.  Bias and time-embedding row are already in the accumulators (kernel
+// prologue); here every wave applies output scale / GEGLU, converts to fp16 and writes its part of the tile into
+// LDS (the idle ring; 160 KB for 256x320), one barrier, then the whole tile leaves as 16-byte coalesced stores.
+// LDS image: rows of bno halves, unpadded, 16-byte chunk c of row r at chunk c ^ (r & 7) (keeps the 8-byte fragment
+// writes and the 16-byte row reads at <= 2-way bank conflicts).  The residual reads are issued before/while staging
+// so that their latency overlaps the LDS round trip, and all arithmetic precedes the first store: on gfx9 stores
+// count in vmcnt like loads, so a load consumed after a store was issued waits for that store's acknowledgement.
+template <int PBM, int BN, int TN, int TM, int WTN, int WTM, bool GEGLU>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][TM], char *smem, int tile_m,
                                             int tile_n, int wm, int wn, int tid, int fr, int fq) {
-  const int bno = p.geglu ? BN / 2 : BN;
-  const int ldc = bno + 8;
-  f16 *sc = (f16 *)smem;
-  const int cpr = bno >> 3;
-  const int ncols_total = p.geglu ? p.n / 2 : p.n;
+  constexpr int bno = GEGLU ? BN / 2 : BN;
+  constexpr int cpr = bno >> 3;                          // 16-byte chunks per row (a multiple of 8)
+  constexpr int TNO = GEGLU ? TN / 2 : TN;
+  constexpr int NCH = PBM * cpr, ITERS = (NCH + 511) / 512, ITERS_A = ITERS / 2;
+  static_assert(cpr % 8 == 0, "chunk swizzle works on aligned groups of 8 chunks");
+  const int ncols_total = GEGLU ? p.n / 2 : p.n;
   const int nstore = p.n_store > 0 ? p.n_store : ncols_total;
+  const int64_t mbase = (int64_t)tile_m * PBM;
 
-  for (int half = 0; half < 2; ++half) {
-    if (wm == half) {
-      if (!p.geglu) {
+  // chunk of this thread in copy-out iteration `it`; chunks that will not be stored read the zero page, which keeps
+  // the prefetch straight-line (loads under divergent branches make the compiler drain vmcnt before each one)
+  auto res_src = [&](const f16 *res, int64_t ldr, int it) -> const f16 * {
+    const int idx = tid + it * 512;
+    const int r = idx / cpr, c = idx - r * cpr;
+    const int64_t m = mbase + r;
+    const int col = tile_n * bno + c * 8;
+    const bool ok = idx < NCH && m < p.m && col + 8 <= nstore;
+    return ok ? res + m * ldr + col : (const f16 *)p.zero;
+  };
+
+  f16x8 q1[ITERS];
+  if (p.res1) {
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          const int nl = wn * WTN + i * 16 + 4 * fq;
-          const int n = tile_n * BN + nl;
-          f32x4 b = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias) b = *(const f32x4 *)(p.bias + n);
+    for (int it = 0; it < ITERS_A; ++it) q1[it] = *(const f16x8 *)res_src(p.res1, p.ldr1, it);
+  }
+  PP_TRACE(4);
+
+  // ---- stage the tile
 #pragma unroll
-          for (int j = 0; j < TM; ++j) {
-            const int ml = j * 16 + fr;                      // row within the half
-            f32x4 v = acc[i][j] + b;
-            if (p.bias2) {
-              const int64_t m = (int64_t)tile_m * PBM + half * WTM + ml;
-              const int64_t brow = m < p.m ? m / p.bias2_rows : 0;
-              v += *(const f32x4 *)(p.bias2 + brow * p.ldb2 + n);
-            }
-            v *= p.oscale;
-            f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-            *(f16x4 *)(sc + ml * ldc + nl) = h;
-          }
-        }
+  for (int i = 0; i < TNO; ++i) {
+    const int col = (GEGLU ? (wn * WTN) / 2 : wn * WTN) + i * 16 + 4 * fq;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      f16x4 o;
+      if constexpr (!GEGLU) {
+        const f32x4 v = acc[i][j] * p.oscale;
+        o = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
       } else {
-        if constexpr (TN % 2 == 0) {
+        const f32x4 h = acc[2 * i][j] * p.oscale, g = acc[2 * i + 1][j];
 #pragma unroll
-          for (int i = 0; i < TN; i += 2) {
-            const int nl = wn * WTN + i * 16 + 4 * fq;
-            const int n = tile_n * BN + nl;
-            f32x4 bh = {0.f, 0.f, 0.f, 0.f}, bg = bh;
-            if (p.bias) {
-              bh = *(const f32x4 *)(p.bias + n);
-              bg = *(const f32x4 *)(p.bias + n + 16);
-            }
-            const int ol = (wn * WTN + i * 16) / 2 + 4 * fq;
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-              const int ml = j * 16 + fr;
-              const f32x4 hv = acc[i][j] + bh, gv = acc[i + 1][j] + bg;
-              f16x4 h;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) h[r] = (f16)(p.oscale * hv[r] * gelu_f(gv[r]));
-              *(f16x4 *)(sc + ml * ldc + ol) = h;
-            }
-          }
-        }
+        for (int r = 0; r < 4; ++r) o[r] = (f16)(h[r] * gelu_f(g[r]));
       }
+      const int row = wm * WTM + j * 16 + fr;
+      *(f16x4 *)(smem + row * (bno * 2) + ((((col >> 3) ^ (fr & 7))) << 4) + (col & 4) * 2) = o;
     }
-    __syncthreads();
-    for (int idx = tid; idx < WTM * cpr; idx += 512) {
-      const int r = idx / cpr, c = idx - r * cpr;
-      const int64_t m = (int64_t)tile_m * PBM + half * WTM + r;
-      if (m >= p.m) continue;
-      const int col = tile_n * bno + c * 8;
-      if (col >= nstore) continue;
-      f16x8 v = *(const f16x8 *)(sc + r * ldc + c * 8);
-      if (p.res1 || p.res2) {
+  }
+  if (p.res1) {
+#pragma unroll
+    for (int it = ITERS_A; it < ITERS; ++it) q1[it] = *(const f16x8 *)res_src(p.res1, p.ldr1, it);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  PP_TRACE(6);
+
+  // ---- copy out
+  f16x8 o[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = tid + it * 512;
+    const int r = idx / cpr, c = idx - r * cpr;      // (idx >= NCH reads idle ring memory, never stored)
+    o[it] = *(const f16x8 *)(smem + r * (bno * 2) + ((c ^ (r & 7)) << 4));
+  }
+  if (p.res1 || p.res2) {
+    constexpr int G = (ITERS + 3) / 4;   // res2 (one GEMM family) is fetched here, in groups to bound registers
+#pragma unroll
+    for (int g0 = 0; g0 < ITERS; g0 += G) {
+      f16x8 q2[G];
+      if (p.res2) {
+#pragma unroll
+        for (int it = g0; it < g0 + G && it < ITERS; ++it) q2[it - g0] = *(const f16x8 *)res_src(p.res2, p.ldr2, it);
+      }
+#pragma unroll
+      for (int it = g0; it < g0 + G && it < ITERS; ++it) {
         float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+        for (int e = 0; e < 8; ++e) f[e] = (float)o[it][e];
         if (p.res1) {
-          const f16x8 q = *(const f16x8 *)(p.res1 + m * p.ldr1 + col);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] += p.r1scale * (float)q[e];
+          for (int e = 0; e < 8; ++e) f[e] += p.r1scale * (float)q1[it][e];
         }
         if (p.res2) {
-          const f16x8 q = *(const f16x8 *)(p.res2 + m * p.ldr2 + col);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] += p.r2scale * (float)q[e];
+          for (int e = 0; e < 8; ++e) f[e] += p.r2scale * (float)q2[it - g0][e];
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (f16)f[e];
-      }
-      if (col + 8 <= nstore) {
-        *(f16x8 *)(p.d + m * p.ldd + col) = v;
-      } else {
-        for (int e = 0; e < nstore - col; ++e) p.d[m * p.ldd + col + e] = v[e];
+        for (int e = 0; e < 8; ++e) o[it][e] = (f16)f[e];
       }
     }
-    __syncthreads();
+  }
+  PP_TRACE(7);
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = tid + it * 512;
+    const int r = idx / cpr, c = idx - r * cpr;
+    const int64_t m = mbase + r;
+    const int col = tile_n * bno + c * 8;
+    if (idx >= NCH || m >= p.m || col >= nstore) continue;
+    if (col + 8 <= nstore) {
+      *(f16x8 *)(p.d + m * p.ldd + col) = o[it];
+    } else {   // ragged last chunk (n_store): the residuals were not prefetched for it
+      for (int e = 0; e < nstore - col; ++e) {
+        float f = (float)o[it][e];
+        if (p.res1) f += p.r1scale * (float)p.res1[m * p.ldr1 + col + e];
+        if (p.res2) f += p.r2scale * (float)p.res2[m * p.ldr2 + col + e];
+        p.d[m * p.ldd + col + e] = (f16)f;
+      }
+    }
   }
 }
 
@@ -158,6 +196,14 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const bool late = wave >= 4;
+  PP_TRACE(0);
+#ifdef SP_GEMM_EXPERIMENTS
+  if (tid == 0 && blockIdx.x < PP_TRACE_WGS) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+    g_pp_trace[blockIdx.x * PP_TRACE_SLOTS + 5] = ((long long)xcc << 32) | hw;
+  }
+#endif
 
   constexpr int GM = BM == 128 ? 8 : 4;
   const int nwg = p.tiles_m * p.tiles_n;
@@ -260,11 +306,33 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
   };
 
   // ---------------------------------------------------------------- main loop
-  f32x4 acc[TN][TM];
+  // Accumulators start at bias (+ the per-image time-embedding row).  The loads are issued ahead of the first
+  // LDS-DMA (so the counted vmcnt waits below still mean "K-step landed") and are consumed after it, i.e. they
+  // complete under the DMA latency instead of at the start of the epilogue.
+  f32x4 acc[TN][TM], bias_v[TN];
+  {
+    const int fr0 = lane & 15, fq0 = lane >> 4;
+    int brow[TM];
+    if (p.bias2) {
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
+      for (int j = 0; j < TM; ++j) {
+        const int m = tile_m * PBM + wm * WTM + j * 16 + fr0;
+        brow[j] = m < p.m ? m / (int)p.bias2_rows : 0;
+      }
+    }
 #pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TN; ++i) {
+      const int n = tile_n * BN + wn * WTN + i * 16 + 4 * fq0;
+      bias_v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bias_v[i] = *(const f32x4 *)(p.bias + n);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias2) acc[i][j] = *(const f32x4 *)(p.bias2 + (int64_t)brow[j] * p.ldb2 + n);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 
   const int nk = p.k >> 5;
   const int fr = lane & 15, fq = lane >> 4;
@@ -286,6 +354,11 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
 #pragma unroll
   for (int s = 0; s < PDIST; ++s)
     if (s < nk) stage_next();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] += bias_v[i];
   // K-step 0 landed (this wave's part), later ones may stay in flight
   {
     const int left = min(PDIST - 1, nk - 1);
@@ -293,6 +366,7 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
   }
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();
+  PP_TRACE(1);
 
   constexpr int dbg = EXP;   // timing experiments only (0 in production): 1 no DMA in loop, 2 no MFMA, 64 no ds_read
   for (int kt = 0; kt < nk; ++kt) {
@@ -347,15 +421,22 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
     __builtin_amdgcn_sched_barrier(0);
   }
   if (!late) __builtin_amdgcn_s_barrier();
+  PP_TRACE(2);
 
-  pp_epilogue<PBM, BN, TN, TM, WTN, WTM>(p, acc, smem, tile_m, tile_n, wm, wn, tid, fr, fq);
+  if (p.geglu) {
+    if constexpr (TN % 2 == 0) pp_epilogue<PBM, BN, TN, TM, WTN, WTM, true>(p, acc, smem, tile_m, tile_n, wm, wn, tid, fr, fq);
+  } else {
+    pp_epilogue<PBM, BN, TN, TM, WTN, WTM, false>(p, acc, smem, tile_m, tile_n, wm, wn, tid, fr, fq);
+  }
+  PP_TRACE(3);
 }
 
 template <int BM, int BN, int EXP = 0>
 int launch_pp(GemmArgs &a, hipStream_t s) {
   constexpr int NSTG = BM == 128 ? 3 : 4;
-  constexpr size_t lds = (size_t)NSTG * (BM + BN) * 64;
-  static_assert((size_t)(BM / 2) * (BN + 8) * 2 <= lds, "half-tile staging must fit in the ring");
+  constexpr size_t ring = (size_t)NSTG * (BM + BN) * 64, tile = (size_t)BM * BN * 2;   // epilogue stages the fp16 tile
+  constexpr size_t lds = ring > tile ? ring : tile;
+  static_assert(lds <= 160 * 1024, "LDS per workgroup");
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)gemm_pp_kernel<BM, BN, EXP>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -393,3 +474,11 @@ int launch_pp(GemmArgs &a, int bm, int bn, hipStream_t s) {
 }
 
 }  // namespace spgemm
+
+#ifdef SP_GEMM_EXPERIMENTS
+extern "C" int sp_debug_pp_trace(long long *host, int n_wgs) {
+  if (n_wgs > spgemm::PP_TRACE_WGS) n_wgs = spgemm::PP_TRACE_WGS;
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(spgemm::g_pp_trace),
+                                  sizeof(long long) * n_wgs * spgemm::PP_TRACE_SLOTS);
+}
+#endif
