@@ -38,13 +38,19 @@ __device__ long long g_pp_trace[PP_TRACE_WGS * PP_TRACE_SLOTS];
 
 __device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
+#ifndef SP_PP_STAGES_192_256
+#define SP_PP_STAGES_192_256 4
+#endif
+constexpr int pp_stages(int bm, int bn) { return bm == 128 ? 3 : (bm == 192 && bn == 256 ? SP_PP_STAGES_192_256 : 4); }
+
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // waits until at most `ksteps_left` K-steps of this wave's DMA (L instructions each) are outstanding
 template <int L>
 __device__ __forceinline__ void wait_dma(int ksteps_left) {
-  if (ksteps_left >= 2) wait_vm<2 * L>();
+  if (ksteps_left >= 3) wait_vm<3 * L>();
+  else if (ksteps_left == 2) wait_vm<2 * L>();
   else if (ksteps_left == 1) wait_vm<L>();
   else wait_vm<0>();
 }
@@ -174,7 +180,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
 template <int BM, int BN, int EXP>
 __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const GemmArgs p) {
   constexpr int PBM = BM;
-  constexpr int PSTAGES = BM == 128 ? 3 : 4, PDIST = PSTAGES - 1;
+  constexpr int PSTAGES = pp_stages(BM, BN), PDIST = PSTAGES - 1;
   constexpr int TN = BN / 4 / 16;                 // weight sub-tiles per wave (4 or 5)
   constexpr int TM = BM / 2 / 16;                 // activation sub-tiles per wave
   constexpr int WTN = BN / 4, WTM = BM / 2;
@@ -351,9 +357,11 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
     ++staged; ++in_tap;
   };
   set_tap(0);
+  PP_TRACE(8);
 #pragma unroll
   for (int s = 0; s < PDIST; ++s)
     if (s < nk) stage_next();
+  PP_TRACE(9);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
 
 template <int BM, int BN, int EXP = 0>
 int launch_pp(GemmArgs &a, hipStream_t s) {
-  constexpr int NSTG = BM == 128 ? 3 : 4;
+  constexpr int NSTG = pp_stages(BM, BN);
   constexpr size_t ring = (size_t)NSTG * (BM + BN) * 64, tile = (size_t)BM * BN * 2;   // epilogue stages the fp16 tile
   constexpr size_t lds = ring > tile ? ring : tile;
   static_assert(lds <= 160 * 1024, "LDS per workgroup");
