@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-rotate", action="store_true",
                     help="N>1: keep the extra step of the balanced split on the first ranks for every video "
                          "(default: rotate it with the video index so no stage is a permanent bottleneck)")
+    ap.add_argument("--fp8-attention", action="store_true",
+                    help="spatial self-attention on fp8-e4m3 MFMA (BASELINE config 5; use with --frames 25 --total-steps 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
@@ -154,7 +156,8 @@ def main():
     from vdpp_amd.models.svd_unet import StableVideoUNet
 
     T = args.total_steps
-    model = StableVideoUNet.from_random_init(StableVideoUNet._default_timestep_schedule(T), seed=0, device=device)
+    model = StableVideoUNet.from_random_init(StableVideoUNet._default_timestep_schedule(T), seed=0, device=device,
+                                             fp8_attention=args.fp8_attention)
     torch.manual_seed(args.seed)  # same dummy conditioning on every rank
     model.set_dummy_conditioning(1, args.frames, args.height, args.width, device,
                                  guidance_scale=args.guidance_scale)
@@ -231,11 +234,12 @@ def main():
             "metric": "steady-state videos/sec (whole node), SVD 14f x 25step",
             "value": value, "unit": "videos/s", "n_gpus": n, "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16+fp8 attention" if args.fp8_attention else "f16", "data": "synthetic",
             "config": {"workload": f"SVD img2vid UNet (1.52B params, random init), latent (1,4,{args.frames},"
                                    f"{args.height},{args.width}) fp16, {T} steps, {passes} UNet pass/step "
                                    f"(guidance_scale={args.guidance_scale}), {conc} videos in flight per GPU "
-                                   f"on separate HIP streams",
+                                   f"on separate HIP streams"
+                                   + (", spatial attention on fp8-e4m3 MFMA" if args.fp8_attention else ""),
                        "stage_steps": stage_sizes(T, n, balanced=True),
                        "stage_steps_rotate_with_video_index": bool(n > 1 and not args.no_rotate),
                        "parallelism": f"step-pipeline pp{n}" if n > 1 else "single GPU (no pipeline split)"},

@@ -128,6 +128,16 @@ int sp_attn_spatial_f16(const void *q, const void *k, const void *v, void *o, in
 int sp_attn_temporal_f16(const void *q, const void *k, const void *v, void *o, int64_t ldq,
                          int64_t ldk, int64_t ldv, int64_t ldo, int batch, int frames, int64_t hw,
                          int heads, float scale, const void *zero_page, void *stream);
+/* fp8 (OCP e4m3fn) MFMA variant of sp_attn_spatial_f16 for BASELINE config 5 ("fp8 MFMA attention path"; the
+ * reference has no fp8 path of its own, its attention is diffusers/xformers behind svd_unet.py:142-199).
+ * Same arguments and fp16 inputs/outputs; q/k/v are quantised per call into `workspace` (Q8, K8 row-major,
+ * V8 transposed per head) and S^T = K.Q^T, O^T += V^T.P^T run on v_mfma_f32_32x32x16_fp8_fp8 with fp32
+ * accumulation and fp32 softmax.  workspace: >= sp_attn_fp8_ws_bytes(batch, seq, heads) bytes, 16-byte aligned,
+ * owned by the caller (never allocated here).  Tolerance vs the fp32 oracle: rel-L2 <= 3e-2. */
+int64_t sp_attn_fp8_ws_bytes(int batch, int seq, int heads);
+int sp_attn_spatial_fp8(const void *q, const void *k, const void *v, void *o, int64_t ldq, int64_t ldk,
+                        int64_t ldv, int64_t ldo, int batch, int seq, int heads, float scale,
+                        void *workspace, int64_t workspace_bytes, const void *zero_page, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Layout / elementwise glue around the UNet (svd_unet.py:382-439).

@@ -49,6 +49,8 @@ def test_rejects_bad_arguments_without_launching():
     assert lib.sp_groupnorm_f16(None, None, None, None, 1, 1, 8, 32, 1e-5, 0, None, 0, None) == -1
     assert lib.sp_layernorm_f16(None, None, 0, None, None, None, None, 1, 8, 1e-5, None) == -1
     assert lib.sp_attn_spatial_f16(None, None, None, None, 64, 64, 64, 64, 1, 1, 1, 0.125, None, None) == -1
+    assert lib.sp_attn_spatial_fp8(None, None, None, None, 64, 64, 64, 64, 1, 1, 1, 0.125, None, 0, None, None) == -1
+    assert lib.sp_attn_fp8_ws_bytes(14, 9216, 5) == 3 * 14 * 9216 * 5 * 64
     assert lib.sp_dummy_unet_f32(*([None] * 9), 1e-5, 1, 0.5, 1, 8, 16, 1, 1, 1, None) == -1
     assert lib.sp_groupnorm_ws_bytes(14, 9216, 320, 32) > 0
 

@@ -47,6 +47,33 @@ def test_unet_forward_matches_oracle(frames, h, w):
     assert err <= 2e-2, f"UNet forward rel_l2={err:.3e}"
 
 
+@pytest.mark.parametrize("frames,h,w", [(25, 16, 16), (14, 16, 24)])
+def test_unet_forward_fp8_attention_matches_oracle(frames, h, w):
+    """BASELINE config 5 path: spatial self-attention on fp8-e4m3 MFMA, everything else fp16.
+    Tolerance: rel-L2 <= 3e-2 against the fp32 oracle, and the fp8 engine must really differ from the
+    fp16 one (i.e. the option is not silently ignored)."""
+    from vdpp_amd.models.unet_hip import SVDUNetHIP
+    cfg, sd, ref, hip16 = _build()
+    hip8 = SVDUNetHIP(cfg, sd, DEV, fp8_attention=True)
+    hip8.FP8_MIN_SEQ = 1          # the test latents are small: force the fp8 kernel at every level
+    assert hip8.fp8_attention and not hip16.fp8_attention
+    g = torch.Generator().manual_seed(12)
+    sample = torch.randn(1, frames, 8, h, w, generator=g).half()
+    ctx = torch.randn(1, 1, cfg.cross_attention_dim, generator=g).half()
+    ids = torch.tensor([[5.0, 127.0, 0.02]]).half()
+    t = 0.73
+    with torch.no_grad():
+        want = ref(sample.float(), t, ctx.float(), ids.float())[0]
+    got8 = hip8(sample.to(DEV), t, ctx.to(DEV), ids.to(DEV))[0].float()
+    got16 = hip16(sample.to(DEV), t, ctx.to(DEV), ids.to(DEV))[0].float()
+    torch.cuda.synchronize()
+    assert torch.isfinite(got8).all()
+    e8, e16 = rel_l2(got8, want), rel_l2(got16, want)
+    print(f"UNet forward rel-L2 vs oracle: fp16 attention {e16:.3e}, fp8 attention {e8:.3e}")
+    assert e8 <= 3e-2, f"fp8-attention UNet forward rel_l2={e8:.3e}"
+    assert e16 <= 2e-2 and not torch.equal(got8, got16)
+
+
 @pytest.mark.parametrize("guidance", [None, 3.0])
 def test_step_matches_oracle_step(guidance):
     """StableVideoUNet.forward (HIP) vs oracle svd_step driving the oracle UNet."""
@@ -347,6 +374,34 @@ def test_benchmark_shape_two_kernel_routes_agree_and_are_deterministic(monkeypat
     upd_a, upd_c = (a.float() - lat.float()).cpu(), (c.float() - lat.float()).cpu()
     err = rel_l2(upd_c, upd_a)
     assert err <= 5e-3, f"kernel routes disagree at the benchmark shape: rel_l2={err:.3e}"
+
+
+def test_config5_shape_fp8_attention_agrees_with_fp16():
+    """BASELINE config 5 at FULL size (SVD-XT: 25 frames, latent (1,4,25,72,128), 30 steps, 1.52 B parameters): the
+    CPU oracle is out of reach, so the check is agreement of one diffusion step with spatial attention on fp8-e4m3
+    MFMA against the same step on the fp16 kernels (which the oracle pins at reduced size), on the UPDATE the step
+    applies.  Tolerance 3e-2 relative L2, plus determinism of the fp8 route."""
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+
+    ts = StableVideoUNet._default_timestep_schedule(30)
+    m16 = StableVideoUNet.from_random_init(ts, seed=0, device=DEV)
+    u8 = type(m16.unet).__new__(type(m16.unet))
+    u8.__dict__.update(m16.unet.__dict__)               # same packed weights, no second 3 GB copy
+    u8.fp8_attention, u8._fp8_ws, u8._gn_ws = True, {}, None
+    m8 = StableVideoUNet(unet=u8, timesteps=ts)
+    assert not m16.unet.fp8_attention
+    for m in (m16, m8):
+        torch.manual_seed(43)
+        m.set_dummy_conditioning(1, 25, 72, 128, torch.device(DEV))
+    lat = (torch.randn(1, 4, 25, 72, 128) * m16.init_noise_sigma).half().to(DEV)
+    a16 = m16(lat, 3)
+    a8 = m8(lat, 3)
+    b8 = m8(lat, 3)
+    assert torch.isfinite(a8).all() and torch.equal(a8, b8)
+    upd16, upd8 = (a16.float() - lat.float()).cpu(), (a8.float() - lat.float()).cpu()
+    err = rel_l2(upd8, upd16)
+    print(f"config-5 step, fp8 vs fp16 attention: rel-L2 of the update {err:.3e}")
+    assert 0 < err <= 3e-2, f"fp8 attention route off at the config-5 shape: rel_l2={err:.3e}"
 
 
 def test_from_pretrained_local_directory(tmp_path):

@@ -44,6 +44,8 @@ SIGNATURES = {
     "sp_groupnorm_f16": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _Z, _P]),
     "sp_layernorm_f16": (_I, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _F, _P]),
     "sp_attn_spatial_f16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _P]),
+    "sp_attn_fp8_ws_bytes": (_L, [_I, _I, _I]),
+    "sp_attn_spatial_fp8": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _L, _P, _P]),
     "sp_attn_temporal_f16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _L, _I, _F, _P, _P]),
     "sp_pack_input_f16": (_I, [_P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     "sp_euler_step_f16": (_I, [_P, _P, _P, _L, _P, _P, _F, _F, _I, _I, _I, _I, _P]),

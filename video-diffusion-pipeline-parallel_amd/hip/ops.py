@@ -141,6 +141,21 @@ def attn_spatial(q, k, v, o, *, ldq, ldk, ldv, ldo, batch, seq, heads, scale=0.1
     return o
 
 
+def attn_fp8_ws_bytes(batch, seq, heads) -> int:
+    return int(load().sp_attn_fp8_ws_bytes(batch, seq, heads))
+
+
+def attn_spatial_fp8(q, k, v, o, workspace, *, ldq, ldk, ldv, ldo, batch, seq, heads, scale=0.125):
+    """fp8-e4m3 MFMA spatial attention (BASELINE config 5); `workspace`: uint8 tensor >= attn_fp8_ws_bytes()."""
+    with _Timed("attn_spatial", 4.0 * batch * heads * seq * seq * 64):
+        _check(load().sp_attn_spatial_fp8(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), ldq, ldk, ldv, ldo,
+                                          batch, seq, heads, scale, workspace.data_ptr(),
+                                          workspace.numel() * workspace.element_size(),
+                                          zero_page(o.device).data_ptr(), _stream()),
+               "sp_attn_spatial_fp8")
+    return o
+
+
 def attn_temporal(q, k, v, o, *, ldq, ldk, ldv, ldo, batch, frames, hw, heads, scale=0.125):
     _check(load().sp_attn_temporal_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), ldq, ldk, ldv, ldo,
                                        batch, frames, hw, heads, scale, zero_page(o.device).data_ptr(), _stream()),

@@ -30,6 +30,7 @@ Fusions baked into the kernel calls:
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 import torch
@@ -104,8 +105,15 @@ class _Run:
 
 
 class SVDUNetHIP:
-    def __init__(self, cfg: UNetConfig, state_dict: dict, device):
+    # fp8 attention pays a quantise pass over q/k/v: below ~1k tokens per frame (the 576- and 144-token levels) the
+    # fp16 kernel is faster (tools/bench_attn.py: 46 vs 56 us at 576 tokens, 1907 vs 1580 us at 9216)
+    FP8_MIN_SEQ = 1024
+
+    def __init__(self, cfg: UNetConfig, state_dict: dict, device, *, fp8_attention: bool | None = None):
+        """``fp8_attention``: run the spatial self-attention on fp8-e4m3 MFMA (BASELINE config 5: "SVD-XT ... with
+        fp8 MFMA attention path"); default off, or ``VDPP_FP8_ATTN=1``.  Everything else stays fp16."""
         self.cfg = cfg
+        self.fp8_attention = (os.environ.get("VDPP_FP8_ATTN") == "1") if fp8_attention is None else bool(fp8_attention)
         self.device = dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("SVDUNetHIP runs on an MI355X HIP device only (no CPU fallback)")
@@ -159,6 +167,7 @@ class SVDUNetHIP:
         self.temb_b = torch.cat(self._temb_b, dim=0).contiguous()
         del self._temb_w, self._temb_b
         self._gn_ws = None
+        self._fp8_ws = {}
 
     # ------------------------------------------------------------------ weight packing
     def _reg_temb(self, sd, p):
@@ -281,6 +290,14 @@ class SVDUNetHIP:
         if temporal:
             ops.attn_temporal(q, k, v, o, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=r.b, frames=r.f, hw=r.hw,
                               heads=heads)
+        elif self.fp8_attention and r.hw >= self.FP8_MIN_SEQ:
+            need = ops.attn_fp8_ws_bytes(r.b * r.f, r.hw, heads)
+            skey = torch.cuda.current_stream(self.device).cuda_stream     # one scratch per HIP stream
+            ws = self._fp8_ws.get(skey)
+            if ws is None or ws.numel() < need:
+                ws = self._fp8_ws[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            ops.attn_spatial_fp8(q, k, v, o, ws, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=r.b * r.f, seq=r.hw,
+                                 heads=heads)
         else:
             ops.attn_spatial(q, k, v, o, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=r.b * r.f, seq=r.hw,
                              heads=heads)
