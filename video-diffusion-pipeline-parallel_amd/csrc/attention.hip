@@ -149,15 +149,20 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
       m_run = m_new;
     }
     const float mb = m_run * scale_log2e;
+    // P -> fp16 pairwise (v_cvt_pk_f16_f32, round-to-nearest: one instruction per pair instead of two converts
+    // and a pack)
     f16x8 pf[2][2];
     float lsum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pv = fast_exp2(sacc[kt][e] * scale_log2e - mb);
-        lsum += pv;
-        pf[kt][e >> 3][e & 7] = (f16)pv;
+      for (int e = 0; e < 16; e += 2) {
+        const float p0 = fast_exp2(sacc[kt][e] * scale_log2e - mb);
+        const float p1 = fast_exp2(sacc[kt][e + 1] * scale_log2e - mb);
+        lsum += p0 + p1;
+        const f16x2 pk = __builtin_convertvector((f32x2){p0, p1}, f16x2);
+        pf[kt][e >> 3][e & 7] = pk[0];
+        pf[kt][e >> 3][(e & 7) + 1] = pk[1];
       }
     l_run += lsum;
 
