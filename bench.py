@@ -151,7 +151,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         init_distributed(backend=resolve_backend(None, simulator=False), rank=rank, world_size=n)
 
-    from oracle.svd_unet_ref import SVDUNetConfig, unet_flops
+    from vdpp_amd.models.unet_spec import UNetConfig, forward_flops
     from vdpp_amd.hip import ops
     from vdpp_amd.models.svd_unet import StableVideoUNet
 
@@ -227,8 +227,8 @@ def main():
     out = None
     if rank == 0:
         value = steps / elapsed
-        flops_all = unet_flops(SVDUNetConfig.svd(), args.frames, args.height, args.width)
-        flops_exec = unet_flops(SVDUNetConfig.svd(), args.frames, args.height, args.width,
+        flops_all = forward_flops(UNetConfig.svd(), args.frames, args.height, args.width)
+        flops_exec = forward_flops(UNetConfig.svd(), args.frames, args.height, args.width,
                                 count_cross_attn_qo=False)["total"]
         out = {
             "metric": "steady-state videos/sec (whole node), SVD 14f x 25step",

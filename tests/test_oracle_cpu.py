@@ -80,3 +80,19 @@ def test_oracle_unet_inventory_matches_product_spec():
     f = unet_flops(SVDUNetConfig.svd(), 14, 72, 128)
     assert abs(f["total"] / 1e12 - 44.69) < 0.01
     assert abs(unet_flops(SVDUNetConfig.svd(), 25, 72, 128)["total"] / 1e12 - 79.83) < 0.01
+
+
+def test_product_flop_model_equals_oracle_flop_model():
+    """bench.py prices the roofline with the package's own FLOP model (vdpp_amd.models.unet_spec.forward_flops, a walk
+    over the contraction list); it must agree term by term with the oracle's independent count, and the contraction
+    list must contain the shapes the engine launches (L0 conv 129,024 x 2,880 x 320, ...)."""
+    from oracle.svd_unet_ref import SVDUNetConfig, unet_flops
+    from vdpp_amd.models.unet_spec import UNetConfig, contractions, forward_flops
+    for cfg_p, cfg_o in ((UNetConfig.svd(), SVDUNetConfig.svd()), (UNetConfig.tiny(64), SVDUNetConfig.tiny(64))):
+        for frames, h, w in ((14, 72, 128), (25, 72, 128), (3, 16, 24)):
+            for qo in (True, False):
+                assert forward_flops(cfg_p, frames, h, w, qo) == unet_flops(cfg_o, frames, h, w, count_cross_attn_qo=qo)
+    shapes = set(contractions(UNetConfig.svd(), 14, 72, 128))
+    assert ("conv3x3", 129024, 320, 2880) in shapes and ("conv3x3", 2016, 1280, 23040) in shapes
+    assert ("attn_s", 70, 9216, 64) in shapes and ("attn_t", 46080, 14, 64) in shapes
+    assert abs(forward_flops(UNetConfig.svd(), 14, 72, 128, False)["total"] / 1e12 - 43.08) < 0.01

@@ -192,3 +192,81 @@ def random_state_dict(cfg: UNetConfig, seed: int = 0, device="cpu", dtype=torch.
 
 def param_count(cfg: UNetConfig) -> int:
     return sum(math.prod(s) for _, s, _ in param_inventory(cfg))
+
+
+# ----------------------------------------------------------------------------------------------
+# FLOP model of one forward (bench.py prices the MFMA roofline with it; SURVEY.md 8(d) inventory)
+# ----------------------------------------------------------------------------------------------
+def contractions(cfg: UNetConfig, frames: int, h: int, w: int) -> Iterator[tuple]:
+    """Every contraction of one UNet forward as ``(kind, m, n, k)`` = an ``[m][k] x [n][k]^T`` product (2*m*n*k
+    FLOPs), plus ``("attn_s" | "attn_t", batch_heads, seq, 64)`` for the attention products (4*bh*seq^2*64).
+    ``kind`` in conv3x3 / tconv / conv1x1 / linear / cross_qo; ``cross_qo`` are the Q and out projections of the
+    single-token cross-attention modules, which cannot change the result and which the HIP engine does not run."""
+    temb = cfg.time_embed_dim
+
+    def resblock(cin, cout, hh, ww):
+        m = frames * hh * ww
+        yield "conv3x3", m, cout, 9 * cin
+        yield "conv3x3", m, cout, 9 * cout
+        yield "tconv", m, cout, 3 * cout
+        yield "tconv", m, cout, 3 * cout
+        if cin != cout:
+            yield "conv1x1", m, cout, cin
+        yield "linear", 1, cout, temb              # time_emb_proj of the spatial and of the temporal block
+        yield "linear", 1, cout, temb
+
+    def transformer(c, hh, ww):
+        m = frames * hh * ww
+        yield "linear", m, c, c                    # proj_in
+        yield "linear", m, c, c                    # proj_out
+        for _ in range(2):                         # spatial block, temporal block
+            yield "linear", m, 3 * c, c            # q, k, v
+            yield "linear", m, c, c                # self-attention out
+            yield "cross_qo", m, c, c              # cross-attention q
+            yield "cross_qo", m, c, c              # cross-attention out
+            yield "linear", m, 8 * c, c            # GEGLU in
+            yield "linear", m, c, 4 * c            # ff out
+        yield "linear", m, 8 * c, c                # temporal ff_in
+        yield "linear", m, c, 4 * c
+        yield "attn_s", frames * (c // 64), hh * ww, 64
+        yield "attn_t", hh * ww * (c // 64), frames, 64
+
+    boc = list(cfg.block_out_channels)
+    hh, ww = h, w
+    yield "conv3x3", frames * h * w, boc[0], 9 * cfg.in_channels
+    ch = boc[0]
+    for i, cout in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            yield from resblock(ch if j == 0 else cout, cout, hh, ww)
+            if cfg.down_has_attn[i]:
+                yield from transformer(cout, hh, ww)
+        ch = cout
+        if i != len(boc) - 1:
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2
+            yield "conv3x3", frames * hh * ww, cout, 9 * cout          # stride-2 downsampler
+    yield from resblock(ch, ch, hh, ww)
+    yield from transformer(ch, hh, ww)
+    yield from resblock(ch, ch, hh, ww)
+    layers = cfg.layers_per_block + 1
+    for in_ch, out_ch, prev, attn, _heads, ups in up_block_plan(cfg):
+        for j in range(layers):
+            skip = in_ch if j == layers - 1 else out_ch
+            yield from resblock((prev if j == 0 else out_ch) + skip, out_ch, hh, ww)
+            if attn:
+                yield from transformer(out_ch, hh, ww)
+        if ups:
+            hh, ww = hh * 2, ww * 2
+            yield "conv3x3", frames * hh * ww, out_ch, 9 * out_ch       # conv after the nearest x2 upsample
+    yield "conv3x3", frames * h * w, cfg.out_channels, 9 * boc[0]
+
+
+def forward_flops(cfg: UNetConfig, frames: int, h: int, w: int, count_cross_attn_qo: bool = True) -> dict:
+    """Algorithmic FLOPs of one forward by op class and in ``total`` (44.69 TFLOP for SVD at 14 x 72 x 128;
+    43.08 with ``count_cross_attn_qo=False`` = what the HIP engine executes)."""
+    tot = {"conv3x3": 0.0, "tconv": 0.0, "conv1x1": 0.0, "linear": 0.0, "attn_s": 0.0, "attn_t": 0.0, "cross_qo": 0.0}
+    for kind, m, n, k in contractions(cfg, frames, h, w):
+        tot[kind] += 4.0 * m * n * n * k if kind.startswith("attn") else 2.0 * m * n * k
+    if count_cross_attn_qo:
+        tot["linear"] += tot["cross_qo"]
+    tot["total"] = sum(v for key, v in tot.items() if key != "cross_qo")
+    return tot
