@@ -16,6 +16,7 @@
 // bank-conflict free; applied on the DMA *source* address, undone in the read address.
 #include "gemm_args.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace spgemm {
 namespace {
@@ -169,6 +170,36 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
         if (p.res1) f += p.r1scale * (float)p.res1[m * p.ldr1 + col + e];
         if (p.res2) f += p.r2scale * (float)p.res2[m * p.ldr2 + col + e];
         p.d[m * p.ldd + col + e] = (f16)f;
+      }
+    }
+  }
+}
+
+// COMPUTE phase of one K-step with this wave's LDS-DMA pieces for K-step kt+3 spread between its MFMAs (an LDS-DMA
+// piece costs the issuing wave ~60 cycles among MFMAs but 100-185 in a phase that also carries ds_reads).  One
+// MFMA stream for every wave; `pieces` is a wave-uniform bit mask (bit pc: issue piece pc; A pieces first).
+template <int TN, int TM, int NAP, int NBP>
+__device__ __forceinline__ void mfma_block(f32x4 (&acc)[TN][TM], const f16x8 (&fw)[TN], const f16x8 (&fa)[TM],
+                                           const f16 *(&aptr)[NAP], int (&astep)[NAP], const f16 *(&bptr)[NBP],
+                                           char *dsa, char *dsb, int pieces) {
+  constexpr int NP = NAP + NBP, NM = TN * TM, GAP = NM / (NP + 1);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+      const int q1 = i * TM + j + 1;
+      if (q1 % GAP == 0 && q1 / GAP <= NP) {
+        const int pc = q1 / GAP - 1;
+        if (pieces & (1 << pc)) {
+          if (pc < NAP) {
+            glds16(aptr[pc], dsa + pc * 8192);
+            aptr[pc] += astep[pc];
+          } else {
+            glds16(bptr[pc - NAP], dsb + (pc - NAP) * 8192);
+            bptr[pc - NAP] += PBK;
+          }
+        }
       }
     }
   }
@@ -377,6 +408,7 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
   PP_TRACE(1);
 
   constexpr int dbg = EXP;   // timing experiments only (0 in production): 1 no DMA in loop, 2 no MFMA, 64 no ds_read
+  constexpr bool DMA_IN_COMPUTE = (dbg & 4) != 0;   // experiment: LDS-DMA pieces interleaved with the MFMAs
   for (int kt = 0; kt < nk; ++kt) {
     // ---- READ phase: operand fragments first, then the LDS-DMA for K-step kt+3.  The DMA instructions
     // queue behind the CU's single 64 B/clk texture-address path (about 100 cycles each when four waves issue
@@ -398,18 +430,43 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
       for (int j = 0; j < TM; ++j) fa[j] = (f16x8){1, 2, 3, 4, 5, 6, 7, (f16)lane};
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!(dbg & 1)) { if (issue) stage_next(); }
-    // K-steps issued beyond kt+1 so far: up to kt+PDIST
-    int left = min(PDIST - 1, nk - 2 - kt);
-    if (left < 0) left = 0;
-    if (late) wait_dma<L_LATE>(left);
+    if constexpr (DMA_IN_COMPUTE) {
+      if (issue && in_tap == cpt) { ++tap; in_tap = 0; set_tap(tap); }     // addresses for the coming pieces
+      // late waves: this wave's pieces of K-step kt+1 must have landed; kt+2 may stay in flight (kt+3 not issued yet)
+      int left = min(PDIST - 2, nk - 2 - kt);
+      if (left < 0) left = 0;
+      if (late) wait_dma<L_LATE>(left);
+    } else {
+      if constexpr (!(dbg & 1)) { if (issue) stage_next(); }
+      // K-steps issued beyond kt+1 so far: up to kt+PDIST
+      int left = min(PDIST - 1, nk - 2 - kt);
+      if (left < 0) left = 0;
+      if (late) wait_dma<L_LATE>(left);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- COMPUTE phase
     __builtin_amdgcn_s_setprio(1);
-    if constexpr (!(dbg & 2)) {
+    if constexpr (DMA_IN_COMPUTE) {
+      char *dsa = smem + stage_slot * STAGE + wave * 1024;
+      char *dsb = dsa + A_BYTES;
+      // pieces this wave owns: A pieces i < A_LOADS_HI or wave < A_SPLIT; B pieces j < B_LOADS_HI or wave < B_SPLIT
+      int pieces = 0;
+      if (issue) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) if (i < A_LOADS_HI || wave < A_SPLIT) pieces |= 1 << i;
+#pragma unroll
+        for (int j = 0; j < B_LOADS_LO; ++j) if (j < B_LOADS_HI || wave < B_SPLIT) pieces |= 1 << (A_LOADS + j);
+      }
+      mfma_block<TN, TM, A_LOADS, B_LOADS_LO>(acc, fw, fa, aptr, astep, bptr, dsa, dsb,
+                                              __builtin_amdgcn_readfirstlane(pieces));
+      if (issue) {
+        stage_slot = stage_slot + 1 == PSTAGES ? 0 : stage_slot + 1;
+        ++staged; ++in_tap;
+      }
+    } else if constexpr (!(dbg & 2)) {
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
 #pragma unroll
@@ -469,8 +526,11 @@ int launch_pp(GemmArgs &a, int bm, int bn, hipStream_t s) {
     case 3: return launch_pp<256, 256, 3>(a, s);
     case 65: return launch_pp<256, 256, 65>(a, s);
     case 67: return launch_pp<256, 256, 67>(a, s);
+    case 4: return launch_pp<256, 256, 4>(a, s);
     default: break;
   }
+  if (bm == 256 && bn == 320 && a.dbg == 4) return launch_pp<256, 320, 4>(a, s);
+  if (bm == 192 && bn == 256 && a.dbg == 4) return launch_pp<192, 256, 4>(a, s);
 #endif
   if (bn == 256) {
     if (bm == 128) return launch_pp<128, 256>(a, s);
