@@ -22,6 +22,7 @@ def run(spec):
     geglu, resid = "g" in flags, "r" in flags
     dev = "cuda"
     taps = {0: 1, 1: 9, 2: 3}[mode]
+    nk = taps * cin // 32
     conv = temporal = None
     if mode == 1:
         h, w = 72, 128
@@ -69,8 +70,8 @@ def run(spec):
           f"prologue {pro.mean():5.2f}  loop {main.mean():6.2f}  epilogue {epi.mean():5.2f}  "
           f"gap {np.mean(gaps) if gaps else 0:5.2f} (p90 {np.percentile(gaps, 90) if gaps else 0:5.2f})  "
           f"start-spread {(t[:, 0].max() - t0) / 100:6.1f}\n"
-          f"{'':30s} prologue parts: setup {np.mean(t[:, 8] - t[:, 0]) / 100:5.2f}  dma-issue {np.mean(t[:, 9] - t[:, 8]) / 100:5.2f}  "
-          f"wait+barrier {np.mean(t[:, 1] - t[:, 9]) / 100:5.2f}\n"
+          f"{'':30s} K loop: {np.mean(t[:, 9] - t[:, 8]) / max(1, nk):8.0f} shader cycles per K-step, "
+          f"clock {np.mean((t[:, 9] - t[:, 8]) / np.maximum(t[:, 2] - t[:, 1], 1)) * 100:6.0f} MHz\n"
           f"{'':30s} epilogue parts: res-issue {np.mean(t[:, 4] - t[:, 2]) / 100:5.2f}  stage+barrier {np.mean(t[:, 6] - t[:, 4]) / 100:5.2f}  "
           f"lds-read+residual {np.mean(t[:, 7] - t[:, 6]) / 100:5.2f}  stores {np.mean(t[:, 3] - t[:, 7]) / 100:5.2f}", flush=True)
 

@@ -33,8 +33,15 @@ __device__ long long g_pp_trace[PP_TRACE_WGS * PP_TRACE_SLOTS];
     if (threadIdx.x == 0 && blockIdx.x < PP_TRACE_WGS)                                              \
       g_pp_trace[blockIdx.x * PP_TRACE_SLOTS + (slot)] = wall_clock64();                            \
   } while (0)
+// shader-clock stamp (s_memtime): with the 100 MHz stamps it gives the clock the K loop really ran at
+#define PP_TRACE_CLK(slot)                                                                          \
+  do {                                                                                              \
+    if (threadIdx.x == 0 && blockIdx.x < PP_TRACE_WGS)                                              \
+      g_pp_trace[blockIdx.x * PP_TRACE_SLOTS + (slot)] = (long long)__builtin_amdgcn_s_memtime();   \
+  } while (0)
 #else
 #define PP_TRACE(slot) do {} while (0)
+#define PP_TRACE_CLK(slot) do {} while (0)
 #endif
 
 __device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
@@ -388,11 +395,9 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
     ++staged; ++in_tap;
   };
   set_tap(0);
-  PP_TRACE(8);
 #pragma unroll
   for (int s = 0; s < PDIST; ++s)
     if (s < nk) stage_next();
-  PP_TRACE(9);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -406,6 +411,7 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();
   PP_TRACE(1);
+  PP_TRACE_CLK(8);
 
   constexpr int dbg = EXP;   // timing experiments only (0 in production): 1 no DMA in loop, 2 no MFMA, 64 no ds_read
   constexpr bool DMA_IN_COMPUTE = (dbg & 4) != 0;   // experiment: LDS-DMA pieces interleaved with the MFMAs
@@ -486,6 +492,7 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
     __builtin_amdgcn_sched_barrier(0);
   }
   if (!late) __builtin_amdgcn_s_barrier();
+  PP_TRACE_CLK(9);
   PP_TRACE(2);
 
   if (p.geglu) {
