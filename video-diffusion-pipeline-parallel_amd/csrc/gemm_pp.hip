@@ -350,33 +350,18 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
   };
 
   // ---------------------------------------------------------------- main loop
-  // Accumulators start at bias (+ the per-image time-embedding row).  The loads are issued ahead of the first
-  // LDS-DMA (so the counted vmcnt waits below still mean "K-step landed") and are consumed after it, i.e. they
-  // complete under the DMA latency instead of at the start of the epilogue.
+  // Accumulators start at bias (+ the per-image time-embedding row) instead of adding them in the epilogue.  The
+  // bias loads are issued ahead of the first LDS-DMA (so the counted vmcnt waits below still mean "K-step landed")
+  // and consumed after it; nothing else delays that first DMA: the 128-160 accumulator registers are written
+  // while it is in flight.  The time-embedding rows (first conv of a residual block only, K >= 2880) are loaded
+  // after the DMA, straight into the accumulators; that tile's first wait then also covers them.
   f32x4 acc[TN][TM], bias_v[TN];
-  {
-    const int fr0 = lane & 15, fq0 = lane >> 4;
-    int brow[TM];
-    if (p.bias2) {
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int m = tile_m * PBM + wm * WTM + j * 16 + fr0;
-        brow[j] = m < p.m ? m / (int)p.bias2_rows : 0;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int n = tile_n * BN + wn * WTN + i * 16 + 4 * fq0;
-      bias_v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bias_v[i] = *(const f32x4 *)(p.bias + n);
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.bias2) acc[i][j] = *(const f32x4 *)(p.bias2 + (int64_t)brow[j] * p.ldb2 + n);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+  for (int i = 0; i < TN; ++i) {
+    bias_v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias_v[i] = *(const f32x4 *)(p.bias + tile_n * BN + wn * WTN + i * 16 + 4 * (lane >> 4));
   }
+  __builtin_amdgcn_sched_barrier(0);
 
   const int nk = p.k >> 5;
   const int fr = lane & 15, fq = lane >> 4;
@@ -399,10 +384,26 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
   for (int s = 0; s < PDIST; ++s)
     if (s < nk) stage_next();
   __builtin_amdgcn_sched_barrier(0);
+  if (p.bias2) {
+    int brow[TM];
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
+    for (int j = 0; j < TM; ++j) {
+      const int m = tile_m * PBM + wm * WTM + j * 16 + fr;
+      brow[j] = m < p.m ? m / (int)p.bias2_rows : 0;
+    }
 #pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] += bias_v[i];
+    for (int i = 0; i < TN; ++i) {
+      const int n = tile_n * BN + wn * WTN + i * 16 + 4 * fq;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = *(const f32x4 *)(p.bias2 + (int64_t)brow[j] * p.ldb2 + n) + bias_v[i];
+      __builtin_amdgcn_sched_barrier(0);      // one row of tiles at a time: 40 address pairs at once would spill
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = bias_v[i];
+  }
   // K-step 0 landed (this wave's part), later ones may stay in flight
   {
     const int left = min(PDIST - 1, nk - 1);
