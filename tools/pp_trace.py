@@ -46,7 +46,7 @@ def run(spec):
     us = e0.elapsed_time(e1) * 1e3
     lib = hip.load()
     nw = 16384
-    buf = np.zeros((nw, 10), dtype=np.int64)
+    buf = np.zeros((nw, 12), dtype=np.int64)
     rc = lib.sp_debug_pp_trace(buf.ctypes.data_as(ctypes.c_void_p), nw)
     assert rc == 0, rc
     bm = int(os.environ.get("SP_GEMM_BM", 256))
@@ -70,6 +70,8 @@ def run(spec):
           f"prologue {pro.mean():5.2f}  loop {main.mean():6.2f}  epilogue {epi.mean():5.2f}  "
           f"gap {np.mean(gaps) if gaps else 0:5.2f} (p90 {np.percentile(gaps, 90) if gaps else 0:5.2f})  "
           f"start-spread {(t[:, 0].max() - t0) / 100:6.1f}\n"
+          f"{'':30s} prologue parts: setup {np.mean(t[:, 10] - t[:, 0]) / 100:5.2f}  dma-issue {np.mean(t[:, 11] - t[:, 10]) / 100:5.2f}  "
+          f"acc-init+wait+barrier {np.mean(t[:, 1] - t[:, 11]) / 100:5.2f}\n"
           f"{'':30s} K loop: {np.mean(t[:, 9] - t[:, 8]) / max(1, nk):8.0f} shader cycles per K-step, "
           f"clock {np.mean((t[:, 9] - t[:, 8]) / np.maximum(t[:, 2] - t[:, 1], 1)) * 100:6.0f} MHz\n"
           f"{'':30s} epilogue parts: res-issue {np.mean(t[:, 4] - t[:, 2]) / 100:5.2f}  stage+barrier {np.mean(t[:, 6] - t[:, 4]) / 100:5.2f}  "

@@ -26,7 +26,7 @@ constexpr int PBK = 32, PNW = 8;
 
 #ifdef SP_GEMM_EXPERIMENTS
 // per-workgroup phase timestamps (100 MHz wall clock) + hardware id, read back by tools/pp_trace.py
-constexpr int PP_TRACE_WGS = 16384, PP_TRACE_SLOTS = 10;
+constexpr int PP_TRACE_WGS = 16384, PP_TRACE_SLOTS = 12;
 __device__ long long g_pp_trace[PP_TRACE_WGS * PP_TRACE_SLOTS];
 #define PP_TRACE(slot)                                                                              \
   do {                                                                                              \
@@ -380,9 +380,11 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
     ++staged; ++in_tap;
   };
   set_tap(0);
+  PP_TRACE(10);
 #pragma unroll
   for (int s = 0; s < PDIST; ++s)
     if (s < nk) stage_next();
+  PP_TRACE(11);
   __builtin_amdgcn_sched_barrier(0);
   if (p.bias2) {
     int brow[TM];
