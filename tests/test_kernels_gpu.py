@@ -202,7 +202,11 @@ def test_gemm_temporal_conv(frames, hw, c):
 
 
 @pytest.mark.parametrize("inst,rows,c,silu", [(3, 200, 64, 1), (14, 9 * 16, 320, 1), (1, 14 * 144, 640, 0),
-                                              (2, 1000, 960, 1), (1, 77, 2560, 1), (5, 331, 1280, 0)])
+                                              (2, 1000, 960, 1), (1, 77, 2560, 1), (5, 331, 1280, 0),
+                                              # single-launch register-resident path (>= 128 (instance, group) slabs):
+                                              (14, 576, 1280, 1), (14, 2304, 640, 0), (14, 576, 2560, 1),
+                                              (4, 700, 1920, 1), (14, 101, 640, 1), (8, 1632, 1280, 0),
+                                              (8, 1633, 1280, 0), (14, 144, 1280, 1)])
 def test_groupnorm(inst, rows, c, silu):
     ops = _ops()
     g = torch.Generator().manual_seed(c + rows)

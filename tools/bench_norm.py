@@ -14,7 +14,7 @@ def timeit(fn, it=20):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / it
-for inst, rows, c in [(14, 9216, 320), (1, 129024, 320), (14, 2304, 640), (14, 2304, 1920), (14, 576, 1280), (14, 9216, 640), (14, 9216, 960)]:
+for inst, rows, c in [(14, 9216, 320), (1, 129024, 320), (14, 2304, 640), (14, 2304, 1920), (14, 576, 1280), (14, 9216, 640), (14, 9216, 960), (14, 144, 1280), (14, 576, 2560), (14, 144, 2560), (14, 2304, 1280)]:
     x = torch.randn(inst * rows, c, device="cuda", dtype=torch.float16)
     y = torch.empty_like(x)
     g = torch.ones(c, device="cuda"); b = torch.zeros(c, device="cuda")
