@@ -1,0 +1,26 @@
+"""Randomised cross-check of sp_gemm_f16 (tools/fuzz_gemm.py): random shapes / gather modes / epilogue flags against fp32
+torch on the CPU, with guard rows and columns around the output (no write outside [0, m) x [0, n_store)).
+Tolerance 3e-3 relative L2 per case (fp16 storage, fp32 accumulation), every kernel family."""
+import os
+import random
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.mark.parametrize("force,bm", [(None, None), ("2", "256"), ("2", "192"), ("2", "128"), ("1", None)])
+def test_gemm_fuzz(monkeypatch, force, bm):
+    import fuzz_gemm
+    if force:
+        monkeypatch.setenv("SP_GEMM_FORCE", force)
+    if bm:
+        monkeypatch.setenv("SP_GEMM_BM", bm)
+    seed = 1000 + int(bm or 0) + int(force or 0)
+    rng, g = random.Random(seed), torch.Generator().manual_seed(seed)
+    worst = max(fuzz_gemm.one(rng, g) for _ in range(30))
+    assert worst <= 3e-3
