@@ -70,13 +70,13 @@ __device__ __forceinline__ void wait_dma(int ksteps_left) {
 // writes and the 16-byte row reads at <= 2-way bank conflicts).  The residual reads are issued before/while staging
 // so that their latency overlaps the LDS round trip, and all arithmetic precedes the first store: on gfx9 stores
 // count in vmcnt like loads, so a load consumed after a store was issued waits for that store's acknowledgement.
-template <int PBM, int BN, int TN, int TM, int WTN, int WTM, bool GEGLU>
+template <int PBM, int BN, int TN, int TM, int WTN, int WTM, bool GEGLU, int NT>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][TM], char *smem, int tile_m,
                                             int tile_n, int wm, int wn, int tid, int fr, int fq) {
   constexpr int bno = GEGLU ? BN / 2 : BN;
   constexpr int cpr = bno >> 3;                          // 16-byte chunks per row (a multiple of 8)
   constexpr int TNO = GEGLU ? TN / 2 : TN;
-  constexpr int NCH = PBM * cpr, ITERS = (NCH + 511) / 512, ITERS_A = ITERS / 2;
+  constexpr int NCH = PBM * cpr, ITERS = (NCH + NT - 1) / NT, ITERS_A = ITERS / 2;
   static_assert(cpr % 8 == 0, "chunk swizzle works on aligned groups of 8 chunks");
   const int ncols_total = GEGLU ? p.n / 2 : p.n;
   const int nstore = p.n_store > 0 ? p.n_store : ncols_total;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
   // chunk of this thread in copy-out iteration `it`; chunks that will not be stored read the zero page, which keeps
   // the prefetch straight-line (loads under divergent branches make the compiler drain vmcnt before each one)
   auto res_src = [&](const f16 *res, int64_t ldr, int it) -> const f16 * {
-    const int idx = tid + it * 512;
+    const int idx = tid + it * NT;
     const int r = idx / cpr, c = idx - r * cpr;
     const int64_t m = mbase + r;
     const int col = tile_n * bno + c * 8;
@@ -130,7 +130,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
   f16x8 o[ITERS];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int idx = tid + it * 512;
+    const int idx = tid + it * NT;
     const int r = idx / cpr, c = idx - r * cpr;      // (idx >= NCH reads idle ring memory, never stored)
     o[it] = *(const f16x8 *)(smem + r * (bno * 2) + ((c ^ (r & 7)) << 4));
   }
@@ -164,7 +164,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
   PP_TRACE(7);
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int idx = tid + it * 512;
+    const int idx = tid + it * NT;
     const int r = idx / cpr, c = idx - r * cpr;
     const int64_t m = mbase + r;
     const int col = tile_n * bno + c * 8;
@@ -185,7 +185,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
 // COMPUTE phase of one K-step with this wave's LDS-DMA pieces for K-step kt+3 spread between its MFMAs (an LDS-DMA
 // piece costs the issuing wave ~60 cycles among MFMAs but 100-185 in a phase that also carries ds_reads).  One
 // MFMA stream for every wave; `pieces` is a wave-uniform bit mask (bit pc: issue piece pc; A pieces first).
-template <int TN, int TM, int NAP, int NBP>
+template <int TN, int TM, int NAP, int NBP, int NWV>
 __device__ __forceinline__ void mfma_block(f32x4 (&acc)[TN][TM], const f16x8 (&fw)[TN], const f16x8 (&fa)[TM],
                                            const f16 *(&aptr)[NAP], int (&astep)[NAP], const f16 *(&bptr)[NBP],
                                            char *dsa, char *dsb, int pieces) {
@@ -200,10 +200,10 @@ __device__ __forceinline__ void mfma_block(f32x4 (&acc)[TN][TM], const f16x8 (&f
         const int pc = q1 / GAP - 1;
         if (pieces & (1 << pc)) {
           if (pc < NAP) {
-            glds16(aptr[pc], dsa + pc * 8192);
+            glds16(aptr[pc], dsa + pc * (NWV * 1024));
             aptr[pc] += astep[pc];
           } else {
-            glds16(bptr[pc - NAP], dsb + (pc - NAP) * 8192);
+            glds16(bptr[pc - NAP], dsb + (pc - NAP) * (NWV * 1024));
             bptr[pc - NAP] += PBK;
           }
         }
@@ -212,34 +212,36 @@ __device__ __forceinline__ void mfma_block(f32x4 (&acc)[TN][TM], const f16x8 (&f
   }
 }
 
-// BM = 256: one workgroup per CU (4-deep ring).  BM = 192: same, for row counts where 256-row tiles leave a
-// third of the CUs idle in the only round (8064 rows x 1280 columns).  BM = 128: 3-deep ring and <= 128 VGPRs so
-// that TWO workgroups share a CU and one's prologue/epilogue overlaps the other's main loop (short-K GEMMs).
+// BM = 256: one workgroup of 8 waves per CU (4-deep ring).  BM = 192: same, for row counts where 256-row tiles leave a
+// third of the CUs idle in the only round (8064 rows x 1280 columns).  BM = 128: FOUR waves (1 x 4, the same 128 x BN/4
+// tile per wave as BM = 256), 3-deep ring, so that TWO workgroups share a CU: each SIMD holds one wave of either, and
+// one workgroup's prologue/epilogue runs under the other's K loop (short-K GEMMs).
 template <int BM, int BN, int EXP>
-__global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const GemmArgs p) {
   constexpr int PBM = BM;
+  constexpr int NWV = BM == 128 ? 4 : 8, NT = NWV * 64, WROWS = NWV / 4;   // waves, threads, wave rows (x 4 columns)
   constexpr int PSTAGES = pp_stages(BM, BN), PDIST = PSTAGES - 1;
   constexpr int TN = BN / 4 / 16;                 // weight sub-tiles per wave (4 or 5)
-  constexpr int TM = BM / 2 / 16;                 // activation sub-tiles per wave
-  constexpr int WTN = BN / 4, WTM = BM / 2;
+  constexpr int TM = BM / WROWS / 16;             // activation sub-tiles per wave
+  constexpr int WTN = BN / 4, WTM = BM / WROWS;
   constexpr int A_BYTES = PBM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
-  // 1-KiB DMA pieces (16 rows x 64 B) are dealt to waves as piece = j*8 + wave; when the count is not a
-  // multiple of 8 it is 4 mod 8, so waves 0-3 ("early" half) issue one piece more than waves 4-7.
+  // 1-KiB DMA pieces (16 rows x 64 B) are dealt to waves as piece = j*NWV + wave; when the count is not a
+  // multiple of NWV it is 4 mod 8, so waves 0-3 ("early" half) issue one piece more than waves 4-7.
   constexpr int A_PIECES = BM / 16, B_PIECES = BN / 16;
-  constexpr int A_LOADS = (A_PIECES + 7) / 8, A_LOADS_HI = A_PIECES / 8;
-  constexpr int A_SPLIT = A_PIECES % 8 == 0 ? 8 : A_PIECES % 8;
-  constexpr int B_LOADS_LO = (B_PIECES + 7) / 8;  // waves 0..(B_PIECES%8 - 1) (all waves if divisible)
-  constexpr int B_LOADS_HI = B_PIECES / 8;        // the other waves
-  constexpr int B_SPLIT = B_PIECES % 8 == 0 ? 8 : B_PIECES % 8;   // waves below this index take B_LOADS_LO
-  static_assert((B_SPLIT == 8 || B_SPLIT == 4) && (A_SPLIT == 8 || A_SPLIT == 4), "wave halves must have uniform DMA counts");
+  constexpr int A_LOADS = (A_PIECES + NWV - 1) / NWV, A_LOADS_HI = A_PIECES / NWV;
+  constexpr int A_SPLIT = A_PIECES % NWV == 0 ? NWV : A_PIECES % NWV;
+  constexpr int B_LOADS_LO = (B_PIECES + NWV - 1) / NWV;  // waves 0..(B_PIECES%NWV - 1) (all waves if divisible)
+  constexpr int B_LOADS_HI = B_PIECES / NWV;              // the other waves
+  constexpr int B_SPLIT = B_PIECES % NWV == 0 ? NWV : B_PIECES % NWV;   // waves below this index take B_LOADS_LO
+  static_assert((B_SPLIT == NWV || B_SPLIT == 4) && (A_SPLIT == NWV || A_SPLIT == 4), "wave halves must have uniform DMA counts");
   constexpr int L_EARLY = A_LOADS + B_LOADS_LO;   // waves 0-3
-  constexpr int L_LATE = (A_SPLIT == 8 ? A_LOADS : A_LOADS_HI) + (B_SPLIT == 8 ? B_LOADS_LO : B_LOADS_HI);   // waves 4-7
+  constexpr int L_LATE = (A_SPLIT == NWV ? A_LOADS : A_LOADS_HI) + (B_SPLIT == NWV ? B_LOADS_LO : B_LOADS_HI);   // waves 4-7
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const bool late = wave >= 4;
+  const bool late = NWV == 8 && wave >= 4;
   PP_TRACE(0);
 #ifdef SP_GEMM_EXPERIMENTS
   if (tid == 0 && blockIdx.x < PP_TRACE_WGS) {
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
   int schunk_a[A_LOADS];
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) {
-    const int r = (i * 8 + wave) * 16 + lrow;
+    const int r = (i * NWV + wave) * 16 + lrow;
     const int m = tile_m * PBM + r;
     a_in[i] = m < p.m && r < PBM;
     schunk_a[i] = (lchunk ^ swz4(r)) * 8;
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
   const f16 *bptr[B_LOADS_LO];
 #pragma unroll
   for (int j = 0; j < B_LOADS_LO; ++j) {
-    const int piece = j * 8 + wave;
+    const int piece = j * NWV + wave;
     const int r = piece * 16 + lrow;
     const int n = tile_n * BN + (r < BN ? r : 0);
     bptr[j] = p.w + (int64_t)n * p.k + (lchunk ^ swz4(r)) * 8;
@@ -336,14 +338,14 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       if (i < A_LOADS_HI || wave < A_SPLIT) {     // wave-uniform
-        glds16(aptr[i], sa + (i * 8 + wave) * 1024);
+        glds16(aptr[i], sa + (i * NWV + wave) * 1024);
         aptr[i] += astep[i];
       }
     }
 #pragma unroll
     for (int j = 0; j < B_LOADS_LO; ++j) {
       if (j < B_LOADS_HI || wave < B_SPLIT) {     // wave-uniform
-        glds16(bptr[j], sb + (j * 8 + wave) * 1024);
+        glds16(bptr[j], sb + (j * NWV + wave) * 1024);
         bptr[j] += PBK;
       }
     }
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
 #pragma unroll
         for (int j = 0; j < B_LOADS_LO; ++j) if (j < B_LOADS_HI || wave < B_SPLIT) pieces |= 1 << (A_LOADS + j);
       }
-      mfma_block<TN, TM, A_LOADS, B_LOADS_LO>(acc, fw, fa, aptr, astep, bptr, dsa, dsb,
+      mfma_block<TN, TM, A_LOADS, B_LOADS_LO, NWV>(acc, fw, fa, aptr, astep, bptr, dsa, dsb,
                                               __builtin_amdgcn_readfirstlane(pieces));
       if (issue) {
         stage_slot = stage_slot + 1 == PSTAGES ? 0 : stage_slot + 1;
@@ -499,9 +501,9 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void gemm_pp_kernel(const G
   PP_TRACE(2);
 
   if (p.geglu) {
-    if constexpr (TN % 2 == 0) pp_epilogue<PBM, BN, TN, TM, WTN, WTM, true>(p, acc, smem, tile_m, tile_n, wm, wn, tid, fr, fq);
+    if constexpr (TN % 2 == 0) pp_epilogue<PBM, BN, TN, TM, WTN, WTM, true, NT>(p, acc, smem, tile_m, tile_n, wm, wn, tid, fr, fq);
   } else {
-    pp_epilogue<PBM, BN, TN, TM, WTN, WTM, false>(p, acc, smem, tile_m, tile_n, wm, wn, tid, fr, fq);
+    pp_epilogue<PBM, BN, TN, TM, WTN, WTM, false, NT>(p, acc, smem, tile_m, tile_n, wm, wn, tid, fr, fq);
   }
   PP_TRACE(3);
 }
@@ -521,7 +523,7 @@ int launch_pp(GemmArgs &a, hipStream_t s) {
   a.tiles_m = (a.m + BM - 1) / BM;
   a.tiles_n = a.n / BN;
   SP_CLEAR_STALE_ERROR();
-  hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, EXP>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, EXP>), dim3(a.tiles_m * a.tiles_n), dim3(BM == 128 ? 256 : 512), lds, s, a);
   SP_CHECK_LAUNCH("sp_gemm_f16(pp)");
   return SP_OK;
 }
