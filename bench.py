@@ -139,7 +139,7 @@ def main():
     n = world
     conc = max(1, args.concurrent if args.concurrent is not None else 2)
     # N>1: 8N videos so that filling/draining the pipe (N-1 stage times inside the bracketed region) stays small
-    steps = args.steps if args.steps is not None else (2 * conc if n == 1 else max(8 * n, 2 * conc))
+    steps = args.steps if args.steps is not None else (4 * conc if n == 1 else max(8 * n, 2 * conc))
     warmup = args.warmup if args.warmup is not None else (conc if n == 1 else max(n, conc))
 
     if os.environ.get("VDPP_SHARE_GPU") == "1":
