@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-rotate", action="store_true",
                     help="N>1: keep the extra step of the balanced split on the first ranks for every video "
                          "(default: rotate it with the video index so no stage is a permanent bottleneck)")
+    ap.add_argument("--no-ring", action="store_true",
+                    help="N>1: chain of stages (rank 0 feeds, last rank finishes) instead of the ring schedule "
+                         "(video i starts on rank i mod N; no pipeline fill/drain inside the timed region)")
     ap.add_argument("--fp8-attention", action="store_true",
                     help="spatial self-attention on fp8-e4m3 MFMA (BASELINE config 5; use with --frames 25 --total-steps 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,9 +169,11 @@ def main():
     spec = LatentSpec(shape=shape, dtype=torch.float16, device=device)
     import logging
     quiet = logging.getLogger("bench.quiet"); quiet.setLevel(logging.ERROR)
+    ring = n > 1 and not args.no_ring
+    rotating = n > 1 and not ring and not args.no_rotate
     stage = PipelineStage(model, PipelineConfig(total_steps=T, world_size=n, rank=rank, timesteps=list(range(T)),
                                                 latent_spec=spec, balanced=True, concurrent_samples=conc,
-                                                rotate=(n > 1 and not args.no_rotate)),
+                                                rotate=rotating, ring=ring),
                           logger=quiet)
     gen = torch.Generator(device=device)
 
@@ -184,7 +189,7 @@ def main():
 
     with torch.no_grad():
         if warmup > 0:
-            stage.run_many(warmup, input_supplier=supplier if rank == 0 else None)
+            stage.run_many(warmup, input_supplier=supplier if (rank == 0 or ring) else None)
             stage.drain()
         fence()
         done_events = []
@@ -195,7 +200,7 @@ def main():
         stage.sample_done_hook = on_done
         t0 = time.perf_counter()
         start_ev = torch.cuda.Event(enable_timing=True); start_ev.record()
-        stage.run_many(steps, input_supplier=(lambda i: supplier(warmup + i)) if rank == 0 else None)
+        stage.run_many(steps, input_supplier=(lambda i: supplier(warmup + i)) if (rank == 0 or ring) else None)
         stage.drain()
         fence()
         elapsed = time.perf_counter() - t0
@@ -209,16 +214,18 @@ def main():
     steady = None
     fill = None
     if rank == n - 1:
-        times = sorted(start_ev.elapsed_time(e) / 1e3 for e in done_events)
+        times = sorted(start_ev.elapsed_time(e) / 1e3 for e in done_events) or [elapsed]
         fill = times[0]
         # completions arrive in groups of `conc` (videos interleaved on streams finish together): drop whole groups
-        # covering the pipeline fill (N-1 samples) and rate the rest group-to-group
-        groups_dropped = max(1, -(-(n - 1) // conc))
+        # covering the pipeline fill (N-1 samples) and rate the rest group-to-group.  Ring schedule: the last rank
+        # finishes one video in N (those that started on rank 0), the others finish elsewhere at the same moments.
+        per_event = n if ring else 1
+        groups_dropped = 1 if ring else max(1, -(-(n - 1) // conc))
         d = groups_dropped * conc
         if len(times) - d >= 1 and times[-1] > times[d - 1]:
-            steady = (len(times) - d) / (times[-1] - times[d - 1])
+            steady = per_event * (len(times) - d) / (times[-1] - times[d - 1])
         else:
-            steady = len(times) / times[-1]
+            steady = per_event * len(times) / times[-1]
     info = torch.tensor([steady or 0.0, fill or 0.0], dtype=torch.float64, device=device)
     if n > 1:
         dist.broadcast(info, src=n - 1)
@@ -241,7 +248,9 @@ def main():
                                    f"on separate HIP streams"
                                    + (", spatial attention on fp8-e4m3 MFMA" if args.fp8_attention else ""),
                        "stage_steps": stage_sizes(T, n, balanced=True),
-                       "stage_steps_rotate_with_video_index": bool(n > 1 and not args.no_rotate),
+                       "stage_steps_rotate_with_video_index": bool(rotating),
+                       "schedule": ("ring: video i starts on rank i mod N and visits every rank once" if ring else
+                                    "chain: rank 0 feeds, last rank finishes") if n > 1 else "single GPU",
                        "parallelism": f"step-pipeline pp{n}" if n > 1 else "single GPU (no pipeline split)"},
             "steady_state_videos_per_s_last_rank": steady, "first_video_latency_s": fill,
             "unet_forward_tflop_algorithmic": flops_all["total"] / 1e12,
@@ -250,8 +259,7 @@ def main():
         # time per UNet forward: at N=1 the whole timed region is forwards; at N>1 the node finishes one video
         # per (bottleneck stage) x (its steps), so this is the per-forward time of the most loaded rank
         per_video = elapsed / steps
-        rotating = n > 1 and not args.no_rotate
-        bottleneck_steps = T / n if rotating else max(stage_sizes(T, n, balanced=True))
+        bottleneck_steps = T / n if (rotating or ring) else max(stage_sizes(T, n, balanced=True))
         ms_forward = 1e3 * per_video / (bottleneck_steps * passes)
         out["ms_per_unet_forward" if n == 1 else "ms_per_unet_forward_bottleneck_stage"] = ms_forward
         out["step_roofline"] = {"bound": "mfma", "achieved": flops_exec / 1e12 / (ms_forward / 1e3),

@@ -75,6 +75,59 @@ def test_gloo_rotating_split_world3(golden_dir):
         assert torch.equal(got, lat)
 
 
+def _ring_worker(rank, ws, golden_dir, init_file, out_file, num_samples):
+    torch.set_num_threads(2)
+    z, model = _load(golden_dir, "dummy_c4h64.npz", 4, 64)
+    init_distributed(backend="gloo", rank=rank, world_size=ws, init_method=f"file://{init_file}")
+    x = torch.from_numpy(z["input"])
+    ts = [6, 5, 4, 3, 2, 1, 0]
+    spec = LatentSpec(shape=x.shape, dtype=torch.float32, device=torch.device("cpu"))
+    quiet = logging.getLogger("quiet"); quiet.setLevel(logging.ERROR)
+    stage = PipelineStage(model, PipelineConfig(total_steps=7, world_size=ws, rank=rank, timesteps=ts, latent_spec=spec,
+                                                balanced=True, ring=True), logger=quiet)
+    started = []
+
+    def supplier(i):
+        started.append(i)
+        return x * (i + 1)
+    with torch.no_grad():
+        outs = stage.run_many(num_samples, input_supplier=supplier)
+    assert started == [i for i in range(num_samples) if i % ws == rank]       # samples start on rank i mod N
+    if rank == ws - 1:
+        torch.save(outs, out_file)
+    else:
+        assert outs is None
+    finalize_distributed()
+
+
+@pytest.mark.parametrize("ws,num_samples", [(2, 4), (2, 5), (3, 7), (4, 8), (4, 2), (3, 1)])
+def test_gloo_ring_schedule_equals_plain_loop(golden_dir, ws, num_samples):
+    """Ring schedule (sample i starts on rank i mod N and walks the ring through stages 0..N-1) over Gloo: every
+    sample equals the plain 7-step loop bit for bit, in order, on the last rank - for sample counts that are and are
+    not multiples of the world size, and for fewer samples than ranks."""
+    with tempfile.TemporaryDirectory() as td:
+        out_file = os.path.join(td, "out.pt")
+        mp.spawn(_ring_worker, args=(ws, golden_dir, os.path.join(td, "init"), out_file, num_samples), nprocs=ws, join=True)
+        outs = torch.load(out_file)
+    z, model = _load(golden_dir, "dummy_c4h64.npz", 4, 64)
+    x = torch.from_numpy(z["input"])
+    assert len(outs) == num_samples
+    for i, got in enumerate(outs):
+        lat = x * (i + 1)
+        with torch.no_grad():
+            for s in [6, 5, 4, 3, 2, 1, 0]:
+                lat = model(lat, s)
+        assert torch.equal(got, lat), f"sample {i}"
+
+
+def test_ring_schedule_requires_supplier_everywhere():
+    spec = LatentSpec(shape=torch.Size((1, 4, 2, 4, 4)), dtype=torch.float32, device=torch.device("cpu"))
+    stage = PipelineStage(lambda l, s: l, PipelineConfig(total_steps=4, world_size=2, rank=1, timesteps=[3, 2, 1, 0],
+                                                          latent_spec=spec, balanced=True, ring=True))
+    with pytest.raises(ValueError, match="every rank needs the input_supplier"):
+        stage.run_many(2, input_supplier=None)
+
+
 def _worker(rank, ws, golden_dir, name, c, hid, init_file, out_file, many):
     torch.set_num_threads(2)
     z, model = _load(golden_dir, name, c, hid)

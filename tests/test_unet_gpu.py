@@ -321,6 +321,85 @@ def test_side_stream_link_with_emulated_stream_ordered_p2p(monkeypatch, conc, ro
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("world,num_samples,conc", [(3, 7, 2), (2, 4, 1), (4, 6, 2)])
+def test_ring_schedule_with_emulated_stream_ordered_p2p(monkeypatch, world, num_samples, conc):
+    """The ring schedule (PipelineConfig.ring) with its GPU transport: `world` ranks emulated by threads of ONE process
+    on one GPU; `batch_isend_irecv` is replaced by stream-ordered mailbox copies per directed link (what a grouped RCCL
+    send/recv provides).  Exercises the event choreography of `_run_many_ring` (compute lanes -> side stream ->
+    compute lanes), the interleaved lanes and the final collection, and checks every sample == the 1-rank result."""
+    import collections
+    import queue
+    import threading
+
+    import vdpp_amd.pipeline.pipeline as pl
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+    from vdpp_amd.pipeline import LatentSpec, PipelineConfig, PipelineStage
+
+    links = collections.defaultdict(queue.Queue)          # (src, dst) -> FIFO of (tensor, ready_event)
+    me = threading.local()
+    FakeOp = collections.namedtuple("FakeOp", "op tensor peer")
+
+    def fake_batch(ops):
+        works = []
+        for op in ops:                                     # sends first: they never block
+            if op.op is pl.dist.isend:
+                ev = torch.cuda.Event()
+                staged = op.tensor.clone()                 # on the issuing stream, ordered behind its wait_event
+                ev.record(torch.cuda.current_stream())
+                links[(me.rank, op.peer)].put((staged, ev))
+                works.append(_FakeWork())
+        for op in ops:
+            if op.op is pl.dist.irecv:
+                def complete(op=op):
+                    staged, ev = links[(op.peer, me.rank)].get(timeout=120)
+                    torch.cuda.current_stream().wait_event(ev)
+                    op.tensor.copy_(staged)
+                works.append(_FakeWork(complete))
+        return works
+
+    monkeypatch.setattr(pl.dist, "P2POp", FakeOp)
+    monkeypatch.setattr(pl.dist, "batch_isend_irecv", fake_batch)
+
+    cfg, sd, ref, hip = _build(seed=31)
+    steps = 7
+    model = StableVideoUNet(unet=hip, timesteps=StableVideoUNet._default_timestep_schedule(steps))
+    torch.manual_seed(9)
+    model.set_dummy_conditioning(1, 3, 8, 16, torch.device(DEV))
+    shape = torch.Size((1, 4, 3, 8, 16))
+    spec = LatentSpec(shape=shape, dtype=torch.float16, device=torch.device(DEV))
+    xs = [(torch.randn(shape) * 20).half().to(DEV) for _ in range(num_samples)]
+
+    def stage(rank, n, ring):
+        return PipelineStage(model, PipelineConfig(total_steps=steps, world_size=n, rank=rank, timesteps=list(range(steps)),
+                                                   latent_spec=spec, balanced=True, concurrent_samples=conc, ring=ring))
+
+    want = stage(0, 1, False).run_many(num_samples, input_supplier=lambda i: xs[i])
+    torch.cuda.synchronize()
+    results, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            me.rank = rank
+            torch.cuda.set_device(0)
+            with torch.no_grad():
+                results[rank] = stage(rank, world, True).run_many(num_samples, input_supplier=lambda i: xs[i])
+            torch.cuda.synchronize()
+        except Exception as exc:       # noqa: BLE001  (reported below, in the main thread)
+            errors.append((rank, repr(exc)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=300)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank is stuck"
+    assert all(q.empty() for q in links.values())
+    assert all(results[r] is None for r in range(world - 1))
+    got = results[world - 1]
+    assert len(got) == num_samples
+    for i, (a, b) in enumerate(zip(want, got)):
+        assert torch.equal(a, b), f"sample {i}"
+
+
 def test_full_width_svd_unet_matches_oracle():
     """The REAL SVD architecture (1.52 B parameters, 320/640/1280 channels, 5/10/20 heads) on a small latent
     (4 frames, 32x32 -> 4,096 token rows at level 0, so the large-tile GEMM kernels run) vs the fp32 oracle.

@@ -32,7 +32,10 @@ reference's blocking behaviour, which is what the golden vectors in ``tests/gold
 
 Extension fields (not in the reference): ``PipelineConfig.balanced`` selects ``assign_steps_balanced`` so 25
 steps can be split over 2/4/8 ranks; ``rotate`` additionally rotates the stages that own the extra step with the
-sample index (``assign_steps_rotating``), so no stage is a permanent bottleneck.
+sample index (``assign_steps_rotating``), so no stage is a permanent bottleneck.  ``ring`` (``run_many`` only) turns
+the chain of stages into a ring: sample ``i`` starts on rank ``i mod N`` and visits ranks ``i, i+1, ...`` (mod N) for
+stages ``0 .. N-1``, so every rank computes from the first moment (no pipeline fill or drain bubble) and every rank
+runs every stage once per N samples (perfectly balanced for any split); see ``PipelineStage._run_many_ring``.
 """
 
 from __future__ import annotations
@@ -48,7 +51,7 @@ from typing import Callable, Deque, Optional
 import torch
 import torch.distributed as dist
 
-from .step_assignment import StepRange, assign_steps, assign_steps_balanced, assign_steps_rotating
+from .step_assignment import StepRange, assign_steps, assign_steps_balanced, assign_steps_rotating, stage_sizes
 
 LOGGER = logging.getLogger(__name__)
 
@@ -78,6 +81,7 @@ class PipelineConfig:
     async_comm: Optional[bool] = None  # None = auto (side-stream RCCL when latent is on a GPU)
     concurrent_samples: int = 1     # run_many: samples interleaved on separate HIP streams of this rank
     rotate: bool = False            # balanced split whose "+1 step" stages rotate with the sample index
+    ring: bool = False              # run_many: ring schedule (sample i starts on rank i mod N); needs a supplier on every rank
 
     def __post_init__(self) -> None:
         if len(self.timesteps) != self.total_steps:
@@ -85,6 +89,14 @@ class PipelineConfig:
 
 
 InputSupplier = Callable[[int], torch.Tensor]
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
 
 
 class _SideStreamLink:
@@ -255,6 +267,8 @@ class PipelineStage:
     ) -> list[torch.Tensor] | None:
         if num_samples <= 0:
             raise ValueError("num_samples must be positive for pipeline execution")
+        if self.config.ring and self.config.world_size > 1:
+            return self._run_many_ring(num_samples, input_supplier)
         first_rank = self.config.rank == 0
         if first_rank and input_supplier is None:
             raise ValueError("rank 0 requires an input_supplier when processing multiple samples")
@@ -323,6 +337,130 @@ class PipelineStage:
                     main.wait_stream(self._streams[j])
             self._log(f"samples {group[0]}..{group[-1]} issued on {len(group)} streams")
         return finished or None
+
+    def _run_many_ring(self, num_samples: int, input_supplier) -> list[torch.Tensor] | None:
+        """Ring schedule (extension).  Samples are taken in batches of N = world_size; in slot ``s`` of a batch this
+        rank runs stage ``s`` (the ``s``-th range of the balanced split) of the sample whose home rank is
+        ``(rank - s) mod N``, then hands it to rank+1 and receives its slot ``s+1`` sample from rank-1, both in ONE
+        ``batch_isend_irecv`` (a grouped RCCL call: safe on a ring, also for N = 2 where both neighbours are the same
+        peer).  In every slot all ranks run the same stage index, so slots line up and nobody waits for a pipeline to
+        fill or drain.  ``concurrent_samples`` batches are interleaved on separate HIP streams.  Finished latents are
+        collected on the last rank at the end (same return contract as the chain: list on the last rank, ``None``
+        elsewhere).  Every rank needs the ``input_supplier`` (it produces the inputs of its home samples)."""
+
+        cfg = self.config
+        n, r = cfg.world_size, cfg.rank
+        if input_supplier is None:
+            raise ValueError("ring schedule: every rank needs the input_supplier (samples start on rank i mod N)")
+        dev = cfg.latent_spec.device
+        cuda = dev.type == "cuda"
+        sizes = stage_sizes(cfg.total_steps, n, balanced=True)
+        starts = [sum(sizes[:j]) for j in range(n)]
+        nxt_rank, prv_rank = (r + 1) % n, (r - 1) % n
+        conc = max(1, cfg.concurrent_samples) if cuda else 1
+        nbatch = (num_samples + n - 1) // n
+        if cuda:
+            if not hasattr(self, "_streams") or len(self._streams) < conc:
+                self._streams = [torch.cuda.Stream(device=dev) for _ in range(conc)]
+            if not hasattr(self, "_ring_stream"):
+                self._ring_stream = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+        finished: dict[int, torch.Tensor] = {}
+
+        def on(j):  # compute stream of interleave lane j (no-op context on CPU)
+            return torch.cuda.stream(self._streams[j]) if cuda else _NullCtx()
+
+        def exchange(outgoing, incoming_lanes):
+            """outgoing: [(lane, tensor)] to rank+1; incoming_lanes: lanes that receive from rank-1.
+            Returns {lane: received tensor}, each lane's stream already ordered behind the transfer."""
+            if not outgoing and not incoming_lanes:
+                return {}
+            ops, got = [], {}
+            if cuda:
+                side = self._ring_stream
+                for j, t in outgoing:
+                    ev = torch.cuda.Event(); ev.record(self._streams[j]); side.wait_event(ev)
+                    t.record_stream(side)
+                with torch.cuda.stream(side):
+                    for j in incoming_lanes:
+                        got[j] = cfg.latent_spec.empty()
+                    for j, t in outgoing:
+                        ops.append(dist.P2POp(dist.isend, t, nxt_rank))
+                    for j in incoming_lanes:
+                        ops.append(dist.P2POp(dist.irecv, got[j], prv_rank))
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()                        # stream-level: the side stream waits, not the host
+                    done = torch.cuda.Event(); done.record(side)
+                for j in incoming_lanes:
+                    self._streams[j].wait_event(done)
+                    got[j].record_stream(self._streams[j])
+                self._ring_keepalive = [t for _, t in outgoing]   # until the next exchange has been ordered behind this one
+            else:
+                for j in incoming_lanes:
+                    got[j] = cfg.latent_spec.empty()
+                for j, t in outgoing:
+                    ops.append(dist.P2POp(dist.isend, t, nxt_rank))
+                for j in incoming_lanes:
+                    ops.append(dist.P2POp(dist.irecv, got[j], prv_rank))
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            return got
+
+        for g0 in range(0, nbatch, conc):
+            lanes = list(range(min(conc, nbatch - g0)))          # lane j <-> batch g0 + j
+            cur: dict[int, torch.Tensor] = {}
+            if cuda:
+                for j in lanes:
+                    self._streams[j].wait_stream(main)
+            for s in range(n):
+                vid = {j: (g0 + j) * n + ((r - s) % n) for j in lanes}
+                live = [j for j in lanes if vid[j] < num_samples]
+                if s == 0:
+                    for j in live:
+                        with on(j):
+                            cur[j] = input_supplier(vid[j]).to(dev)
+                steps = list(cfg.timesteps[starts[s]: starts[s] + sizes[s]])
+                if len(steps) != sizes[s]:
+                    raise RuntimeError("Local timestep slice length mismatch with step range.")
+                for step in steps:                                # round-robin over the interleaved samples
+                    for j in live:
+                        with on(j):
+                            cur[j] = self.model(cur[j], step)
+                if s == n - 1:
+                    for j in live:
+                        finished[vid[j]] = cur.pop(j)
+                        if self.sample_done_hook is not None:
+                            with on(j):
+                                self.sample_done_hook(vid[j])
+                    continue
+                incoming = [j for j in lanes if (g0 + j) * n + ((r - s - 1) % n) < num_samples]
+                got = exchange([(j, cur[j]) for j in live], incoming)
+                cur = got
+            self._log(f"ring batches {g0}..{g0 + len(lanes) - 1} issued")
+        if cuda:
+            for st in self._streams[:conc]:
+                main.wait_stream(st)
+            for t in finished.values():
+                t.record_stream(main)
+
+        # ---- collect on the last rank (sample i finished on rank (i mod N) - 1)
+        last = n - 1
+        ops, out = [], {}
+        if r == last:
+            for i in range(num_samples):
+                src = ((i % n) - 1) % n
+                if src == last:
+                    out[i] = finished[i]
+                else:
+                    out[i] = cfg.latent_spec.empty()
+                    ops.append(dist.P2POp(dist.irecv, out[i], src))
+        else:
+            for i in sorted(finished):
+                ops.append(dist.P2POp(dist.isend, finished[i], last))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return [out[i] for i in range(num_samples)] if r == last else None
 
     def _process_single_latent(
         self, input_latent: torch.Tensor | None, sample_idx: int | None
