@@ -153,6 +153,7 @@ def main():
     if n > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         init_distributed(backend=resolve_backend(None, simulator=False), rank=rank, world_size=n)
+        dist.barrier()      # create the world communicator collectively, before the first grouped send/recv needs it
 
     from vdpp_amd.models.unet_spec import UNetConfig, forward_flops
     from vdpp_amd.hip import ops
