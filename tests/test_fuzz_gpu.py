@@ -24,3 +24,13 @@ def test_gemm_fuzz(monkeypatch, force, bm):
     rng, g = random.Random(seed), torch.Generator().manual_seed(seed)
     worst = max(fuzz_gemm.one(rng, g) for _ in range(30))
     assert worst <= 3e-3
+
+
+def test_attention_and_norm_fuzz():
+    """tools/fuzz_misc.py: random shapes of the spatial (fp16 and fp8) / temporal attention, GroupNorm (three-launch
+    and single-launch paths) and LayerNorm kernels against fp32 torch, with guard rows around every output.
+    Tolerances: 3e-3 relative L2 (fp16 kernels), 3e-2 for the fp8 attention against the e4m3-rounded inputs."""
+    import fuzz_misc
+    rng, g = random.Random(77), torch.Generator().manual_seed(77)
+    for _ in range(60):
+        fuzz_misc.one(rng, g)

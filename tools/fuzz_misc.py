@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Randomised cross-checks of the attention and normalisation kernels against fp32 torch (CPU), with guard rows around
+every output (no write outside the rows the call owns).  usage: fuzz_misc.py [cases] [seed]"""
+import os, random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.nn.functional as F
+import vdpp_amd  # noqa
+from vdpp_amd.hip import ops
+
+DEV = "cuda"
+G = 2
+
+
+def h(t):
+    return t.half().float()
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def guarded(rows, cols):
+    buf = torch.full((rows + 2 * G, cols), 9.0, dtype=torch.float16, device=DEV)
+    return buf, buf[G:G + rows]
+
+
+def check_guard(buf, rows, what):
+    got = buf.float().cpu()
+    assert torch.all(got[:G] == 9.0) and torch.all(got[G + rows:] == 9.0), "guard rows written: " + what
+    assert torch.isfinite(got).all(), "non-finite output: " + what
+    return got[G:G + rows]
+
+
+def attn_spatial(rng, g, fp8):
+    batch, heads = rng.choice([1, 2, 5]), rng.choice([1, 2, 5])
+    seq = rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 200, 577, 1000, 1153])
+    c = heads * 64
+    qkv = h(torch.randn(batch * seq, 3 * c, generator=g) * rng.choice([0.5, 1.0, 2.0]))
+    d = qkv.half().to(DEV)
+    buf, o = guarded(batch * seq, c)
+    kw = dict(ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=batch, seq=seq, heads=heads)
+    if fp8:
+        ws = torch.empty(ops.attn_fp8_ws_bytes(batch, seq, heads), dtype=torch.uint8, device=DEV)
+        ops.attn_spatial_fp8(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o, ws, **kw)
+        x = qkv.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+        tol = 3e-2
+    else:
+        ops.attn_spatial(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o, **kw)
+        x, tol = qkv, 3e-3
+    torch.cuda.synchronize()
+    q, k, v = [t.reshape(batch, seq, heads, 64).transpose(1, 2) for t in x.split(c, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(batch * seq, c)
+    what = f"attn_spatial{'_fp8' if fp8 else ''} batch={batch} seq={seq} heads={heads}"
+    e = rel_l2(check_guard(buf, batch * seq, what), ref)
+    assert e <= tol, f"rel_l2={e:.3e}: {what}"
+    return e
+
+
+def attn_temporal(rng, g):
+    batch, heads, frames, hw = rng.choice([1, 2]), rng.choice([1, 3, 5]), rng.choice([1, 2, 14, 16, 17, 25, 32]), rng.choice([1, 3, 50, 257])
+    c = heads * 64
+    rows = batch * frames * hw
+    qkv = h(torch.randn(rows, 3 * c, generator=g))
+    d = qkv.half().to(DEV)
+    buf, o = guarded(rows, c)
+    ops.attn_temporal(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=batch,
+                      frames=frames, hw=hw, heads=heads)
+    torch.cuda.synchronize()
+    q, k, v = [t.reshape(batch, frames, hw, heads, 64).permute(0, 2, 3, 1, 4) for t in qkv.split(c, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v).permute(0, 3, 1, 2, 4).reshape(rows, c)
+    what = f"attn_temporal batch={batch} frames={frames} hw={hw} heads={heads}"
+    e = rel_l2(check_guard(buf, rows, what), ref)
+    assert e <= 3e-3, f"rel_l2={e:.3e}: {what}"
+    return e
+
+
+def groupnorm(rng, g):
+    inst = rng.choice([1, 2, 5, 14])
+    rows = rng.choice([1, 7, 100, 144, 576, 577, 1000, 1632, 1633, 2304])
+    c = rng.choice([64, 320, 640, 960, 1280, 1920, 2560])
+    silu = rng.random() < 0.5
+    eps = rng.choice([1e-5, 1e-6])
+    x = h(torch.randn(inst, rows, c, generator=g) * rng.choice([0.3, 2.0]) + rng.choice([0.0, 0.7, -3.0]))
+    gamma = torch.randn(c, generator=g); beta = torch.randn(c, generator=g)
+    ref = F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, eps=eps)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1).reshape(inst * rows, c)
+    ws = torch.empty(ops.groupnorm_ws_bytes(inst, rows, c, 32), dtype=torch.uint8, device=DEV)
+    buf, y = guarded(inst * rows, c)
+    ops.groupnorm(x.half().to(DEV).reshape(inst * rows, c), gamma.to(DEV), beta.to(DEV), y, instances=inst, rows=rows, c=c,
+                  groups=32, eps=eps, silu=silu, ws=ws)
+    torch.cuda.synchronize()
+    what = f"groupnorm inst={inst} rows={rows} c={c} silu={silu}"
+    e = rel_l2(check_guard(buf, inst * rows, what), ref)
+    assert e <= 3e-3, f"rel_l2={e:.3e}: {what}"
+    return e
+
+
+def layernorm(rng, g):
+    rows = rng.choice([1, 3, 64, 257, 1000, 4099])
+    c = rng.choice([64, 320, 640, 1280])
+    x = h(torch.randn(rows, c, generator=g) * 2 + 0.5)
+    gamma = torch.randn(c, generator=g); beta = torch.randn(c, generator=g)
+    buf, y = guarded(rows, c)
+    ops.layernorm(x.half().to(DEV), gamma.to(DEV), beta.to(DEV), y, rows=rows, c=c)
+    torch.cuda.synchronize()
+    what = f"layernorm rows={rows} c={c}"
+    e = rel_l2(check_guard(buf, rows, what), F.layer_norm(x, (c,), gamma, beta))
+    assert e <= 3e-3, f"rel_l2={e:.3e}: {what}"
+    return e
+
+
+def one(rng, g):
+    kind = rng.choice(["as", "as", "as8", "at", "gn", "gn", "ln"])
+    if kind == "as": return attn_spatial(rng, g, False)
+    if kind == "as8": return attn_spatial(rng, g, True)
+    if kind == "at": return attn_temporal(rng, g)
+    if kind == "gn": return groupnorm(rng, g)
+    return layernorm(rng, g)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng, g = random.Random(seed), torch.Generator().manual_seed(seed)
+    for i in range(cases):
+        one(rng, g)
+        if (i + 1) % 25 == 0:
+            print(f"{i + 1} cases ok", flush=True)
+    print(f"fuzz_misc: {cases} cases passed (seed {seed})")
+
+
+if __name__ == "__main__":
+    main()
