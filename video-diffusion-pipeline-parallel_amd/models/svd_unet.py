@@ -113,10 +113,11 @@ class StableVideoUNet(nn.Module):
 
         from safetensors.torch import load_file
 
+        files = sorted(n for n in os.listdir(unet_dir) if n.endswith(".safetensors"))
+        fp16_files = [n for n in files if ".fp16." in n]       # the hub layout ships both variants: read one of them
         sd = {}
-        for name in sorted(os.listdir(unet_dir)):
-            if name.endswith(".safetensors"):
-                sd.update(load_file(os.path.join(unet_dir, name)))
+        for name in (fp16_files or files):
+            sd.update(load_file(os.path.join(unet_dir, name)))
         if not sd:
             raise ValueError(f"no *.safetensors weights under '{unet_dir}'")
         cfg = UNetConfig.svd()
