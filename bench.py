@@ -171,6 +171,25 @@ def main():
     import logging
     quiet = logging.getLogger("bench.quiet"); quiet.setLevel(logging.ERROR)
     ring = n > 1 and not args.no_ring
+    if ring:
+        # self-test of the grouped neighbour exchange the ring schedule relies on (also warms the communicator);
+        # if any rank cannot do it, every rank falls back to the chain schedule
+        ok = torch.ones(1, device=device)
+        try:
+            probe_out = torch.full((4,), float(rank), device=device)
+            probe_in = torch.empty(4, device=device)
+            works = dist.batch_isend_irecv([dist.P2POp(dist.isend, probe_out, (rank + 1) % n),
+                                            dist.P2POp(dist.irecv, probe_in, (rank - 1) % n)])
+            for wk in works:
+                wk.wait()
+            torch.cuda.synchronize(device)
+            if float(probe_in[0]) != float((rank - 1) % n):
+                ok.zero_()
+        except Exception as exc:  # noqa: BLE001
+            print(f"[rank {rank}] ring self-test failed ({exc!r}); using the chain schedule", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        ring = bool(ok.item() > 0)
     rotating = n > 1 and not ring and not args.no_rotate
     stage = PipelineStage(model, PipelineConfig(total_steps=T, world_size=n, rank=rank, timesteps=list(range(T)),
                                                 latent_spec=spec, balanced=True, concurrent_samples=conc,
