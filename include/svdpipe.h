@@ -88,6 +88,12 @@ int sp_gemm_f16(const sp_gemm_desc *desc, void *stream);
  * silu_in / silu_out apply SiLU to the input vector / output. `rows` independent input vectors. */
 int sp_gemv_f16(const void *x, int64_t ldx, const void *w, const float *b, float *y, void *y_f16,
                 int64_t ldy, int rows, int n, int k, int silu_in, int silu_out, void *stream);
+/* `batch` independent GEMVs of one shape in a single launch (the 32 single-token cross-attention modules and the 16
+ * frame-position MLPs of a forward are grouped by width).  Strides are in elements between consecutive problems;
+ * x_stride = 0 shares the input, b may be NULL.  Otherwise as sp_gemv_f16. */
+int sp_gemv_batched_f16(const void *x, int64_t ldx, int64_t x_stride, const void *w, int64_t w_stride,
+                        const float *b, int64_t b_stride, float *y, void *y_f16, int64_t ldy, int64_t y_stride,
+                        int batch, int rows, int n, int k, int silu_in, int silu_out, void *stream);
 
 /* Sinusoidal embedding [cos | sin] (diffusers Timesteps(dim, flip_sin_to_cos=True, shift=0)) of
  * `count` fp32 values read from device memory; writes fp16 [count][dim]. */

@@ -390,6 +390,21 @@ def test_attention_temporal(batch, frames, hw, heads):
     check(o, ref, l2=3e-3, mx=2e-2)
 
 
+def test_gemv_batched():
+    """sp_gemv_batched_f16: a batch of same-shape GEMVs in one launch, shared input (x_stride 0) and per-problem input."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    batch, rows, n, k = 5, 3, 200, 320
+    w = h(torch.randn(batch, n, k, generator=g) / math.sqrt(k)); b = torch.randn(batch, n, generator=g)
+    x_shared = h(torch.randn(rows, k, generator=g)); x_each = h(torch.randn(batch, rows, k, generator=g))
+    y32 = torch.empty(batch, rows, n, dtype=torch.float32, device=DEV)
+    ops.gemv_batched(x_shared.half().to(DEV), w.half().to(DEV), b.to(DEV), batch=batch, n=n, k=k, rows=rows, x_stride=0, y32=y32)
+    check(y32, torch.einsum("rk,gnk->grn", x_shared, w) + b[:, None, :], l2=1e-5, mx=1e-5)
+    y16 = torch.empty(batch, rows, n, dtype=torch.float16, device=DEV)
+    ops.gemv_batched(x_each.half().to(DEV), w.half().to(DEV), None, batch=batch, n=n, k=k, rows=rows, y16=y16, silu_out=True)
+    check(y16, F.silu(torch.einsum("grk,gnk->grn", x_each, w)))
+
+
 def test_pack_input_and_euler():
     ops = _ops()
     g = torch.Generator().manual_seed(2)

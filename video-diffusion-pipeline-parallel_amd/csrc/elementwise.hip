@@ -84,14 +84,21 @@ __global__ void add_rowvec_kernel(const f16 *__restrict__ x, const float *__rest
 }
 
 // one wave per output element n: y[row][n] = W[n][:] . act(x[row][:]) + b[n]
+// blockIdx.z = problem of a batch of same-shape GEMVs (strides in elements; 0 = shared operand)
 __global__ __launch_bounds__(256) void gemv_kernel(const f16 *__restrict__ x, int64_t ldx,
                                                    const f16 *__restrict__ w, const float *__restrict__ b,
                                                    float *__restrict__ y, f16 *__restrict__ yh, int64_t ldy,
-                                                   int n, int k, int silu_in, int silu_out) {
+                                                   int n, int k, int silu_in, int silu_out, int64_t xs,
+                                                   int64_t ws, int64_t bs, int64_t ys) {
   const int lane = threadIdx.x & 63;
   const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int row = blockIdx.y;
   if (col >= n) return;
+  const int64_t g = blockIdx.z;
+  x += g * xs; w += g * ws;
+  if (b) b += g * bs;
+  if (y) y += g * ys;
+  if (yh) yh += g * ys;
   const f16 *wr = w + (int64_t)col * k;
   const f16 *xr = x + (int64_t)row * ldx;
   float acc = 0.f;
@@ -188,8 +195,25 @@ extern "C" int sp_gemv_f16(const void *x, int64_t ldx, const void *w, const floa
   SP_REQUIRE(rows > 0 && n > 0 && k > 0 && k % 8 == 0 && ldx % 8 == 0, "sp_gemv_f16: bad shape rows=%d n=%d k=%d", rows, n, k);
   SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(gemv_kernel, dim3((n + 3) / 4, rows), dim3(256), 0, (hipStream_t)stream, (const f16 *)x,
-                     ldx, (const f16 *)w, b, y, (f16 *)y_f16, ldy, n, k, silu_in, silu_out);
+                     ldx, (const f16 *)w, b, y, (f16 *)y_f16, ldy, n, k, silu_in, silu_out, (int64_t)0, (int64_t)0,
+                     (int64_t)0, (int64_t)0);
   SP_CHECK_LAUNCH("sp_gemv_f16");
+  return SP_OK;
+}
+
+extern "C" int sp_gemv_batched_f16(const void *x, int64_t ldx, int64_t x_stride, const void *w, int64_t w_stride,
+                                   const float *b, int64_t b_stride, float *y, void *y_f16, int64_t ldy,
+                                   int64_t y_stride, int batch, int rows, int n, int k, int silu_in, int silu_out,
+                                   void *stream) {
+  SP_REQUIRE(x && w && (y || y_f16), "sp_gemv_batched_f16: null pointer");
+  SP_REQUIRE(batch > 0 && batch <= 65535 && rows > 0 && rows <= 65535 && n > 0 && k > 0 && k % 8 == 0 && ldx % 8 == 0 &&
+                 x_stride % 8 == 0 && w_stride % 8 == 0,
+             "sp_gemv_batched_f16: bad shape batch=%d rows=%d n=%d k=%d", batch, rows, n, k);
+  SP_CLEAR_STALE_ERROR();
+  hipLaunchKernelGGL(gemv_kernel, dim3((n + 3) / 4, rows, batch), dim3(256), 0, (hipStream_t)stream, (const f16 *)x,
+                     ldx, (const f16 *)w, b, y, (f16 *)y_f16, ldy, n, k, silu_in, silu_out, x_stride, w_stride,
+                     b_stride, y_stride);
+  SP_CHECK_LAUNCH("sp_gemv_batched_f16");
   return SP_OK;
 }
 

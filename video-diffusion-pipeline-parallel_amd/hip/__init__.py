@@ -39,6 +39,7 @@ SIGNATURES = {
     "sp_version": (_I, []),
     "sp_gemm_f16": (_I, [ctypes.POINTER(GemmDesc), _P]),
     "sp_gemv_f16": (_I, [_P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "sp_gemv_batched_f16": (_I, [_P, _L, _L, _P, _L, _P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P]),
     "sp_sinusoid_f16": (_I, [_P, _P, _I, _I, _P]),
     "sp_groupnorm_ws_bytes": (_Z, [_I, _L, _I, _I]),
     "sp_groupnorm_f16": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _Z, _P]),

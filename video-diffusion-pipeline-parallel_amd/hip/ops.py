@@ -111,6 +111,18 @@ def gemv(x, w, b, *, n, k, rows=1, ldx=None, y32=None, y16=None, ldy=None, silu_
                               int(silu_in), int(silu_out), _stream()), "sp_gemv_f16")
 
 
+def gemv_batched(x, w, b, *, batch, n, k, rows=1, ldx=None, x_stride=None, y32=None, y16=None, ldy=None,
+                 silu_in=False, silu_out=False):
+    """``batch`` same-shape GEMVs in one launch: w [batch][n][k], b [batch][n] or None, y [batch][rows][n];
+    x [batch][rows][k], or one shared [rows][k] input with ``x_stride=0``."""
+    ldx = int(ldx if ldx is not None else k)
+    ldy = int(ldy if ldy is not None else n)
+    xs = int(rows * ldx if x_stride is None else x_stride)
+    _check(load().sp_gemv_batched_f16(_f16(x, "x").data_ptr(), ldx, xs, _f16(w, "w").data_ptr(), n * k, _ptr(b), n,
+                                      _ptr(y32), _ptr(y16), ldy, rows * ldy, batch, rows, n, k, int(silu_in),
+                                      int(silu_out), _stream()), "sp_gemv_batched_f16")
+
+
 def sinusoid(values32, out16, count, dim):
     _check(load().sp_sinusoid_f16(values32.data_ptr(), out16.data_ptr(), count, dim, _stream()), "sp_sinusoid_f16")
 

@@ -94,6 +94,8 @@ class _Run:
     ctx16: torch.Tensor         # fp16 [B][cross_dim]
     gn_ws: torch.Tensor
     frame_ids: torch.Tensor     # fp32 [F] = arange(F)
+    cross: dict = None          # width C -> fp32 [modules][B][C]: to_out(to_v(ctx)) + b of every cross-attention of that width
+    pos: dict = None            # width C -> fp16 [transformers][F][C]: frame position embeddings
 
     @property
     def hw(self):
@@ -120,6 +122,7 @@ class SVDUNetHIP:
         ops.load()  # fail loudly now if the extension is missing
         sd = state_dict
         self._temb_w, self._temb_b, self._temb_n = [], [], 0
+        self._xf_all = []
         boc = list(cfg.block_out_channels)
         g = cfg.norm_groups
 
@@ -166,6 +169,7 @@ class SVDUNetHIP:
         self.temb_w = torch.cat(self._temb_w, dim=0).contiguous()
         self.temb_b = torch.cat(self._temb_b, dim=0).contiguous()
         del self._temb_w, self._temb_b
+        self._group_small_gemvs()
         self._gn_ws = None
         self._fp8_ws = {}
 
@@ -203,6 +207,56 @@ class SVDUNetHIP:
                     ob=_f32(sd[p + ".to_out.0.bias"], dev))
 
     def _transformer(self, sd, p, c):
+        xf = self._transformer_params(sd, p, c)
+        self._xf_all.append(xf)
+        return xf
+
+    def _group_small_gemvs(self):
+        """The 32 single-token cross-attention modules and the 16 frame-position MLPs are M <= 25 GEMVs: stack their
+        weights by width so that a forward issues 5 batched launches per width instead of ~110 tiny ones."""
+        self._small = {}
+        by_c = {}
+        for xf in self._xf_all:
+            by_c.setdefault(xf["c"], []).append(xf)
+        for c, xfs in by_c.items():
+            xs = [m for xf in xfs for m in (xf["s_x"], xf["t_x"])]
+            sm = dict(G=len(xs), T=len(xfs),
+                      Wv=torch.stack([m["v"] for m in xs]).contiguous(), Wo=torch.stack([m["o"] for m in xs]).contiguous(),
+                      bo=torch.stack([m["ob"] for m in xs]).contiguous(),
+                      W1=torch.stack([xf["pe1"].w for xf in xfs]).contiguous(),
+                      b1=torch.stack([xf["pe1"].bias for xf in xfs]).contiguous(),
+                      W2=torch.stack([xf["pe2"].w for xf in xfs]).contiguous(),
+                      b2=torch.stack([xf["pe2"].bias for xf in xfs]).contiguous())
+            for g, m in enumerate(xs):
+                m.clear()
+                m["grp"] = (c, g)
+            for t, xf in enumerate(xfs):
+                del xf["pe1"], xf["pe2"]
+                xf["pos_idx"] = t
+            self._small[c] = sm
+        del self._xf_all
+
+    def _small_gemvs(self, r: _Run):
+        """Per forward: every cross-attention vector and every frame position embedding (see _group_small_gemvs)."""
+        dev = self.device
+        cross = r.ctx16.shape[1]
+        r.cross, r.pos = {}, {}
+        for c, sm in self._small.items():
+            g, t = sm["G"], sm["T"]
+            v16 = torch.empty((g, r.b, c), dtype=torch.float16, device=dev)
+            ops.gemv_batched(r.ctx16, sm["Wv"], None, batch=g, n=c, k=cross, rows=r.b, x_stride=0, y16=v16)
+            cv = torch.empty((g, r.b, c), dtype=torch.float32, device=dev)
+            ops.gemv_batched(v16, sm["Wo"], sm["bo"], batch=g, n=c, k=c, rows=r.b, y32=cv)
+            r.cross[c] = cv
+            sin = torch.empty((r.f, c), dtype=torch.float16, device=dev)
+            ops.sinusoid(r.frame_ids, sin, r.f, c)
+            pe_h = torch.empty((t, r.f, 4 * c), dtype=torch.float16, device=dev)
+            ops.gemv_batched(sin, sm["W1"], sm["b1"], batch=t, n=4 * c, k=c, rows=r.f, x_stride=0, y16=pe_h, silu_out=True)
+            pe = torch.empty((t, r.f, c), dtype=torch.float16, device=dev)
+            ops.gemv_batched(pe_h, sm["W2"], sm["b2"], batch=t, n=c, k=4 * c, rows=r.f, y16=pe)
+            r.pos[c] = pe
+
+    def _transformer_params(self, sd, p, c):
         dev = self.device
         b, t = p + ".transformer_blocks.0", p + ".temporal_transformer_blocks.0"
         alpha = float(torch.sigmoid(sd[p + ".time_mixer.mix_factor"].float()).item())
@@ -273,13 +327,9 @@ class SVDUNetHIP:
         return self._gemm(r, p["tc2"], t, oscale=1.0 - p["alpha"], res1=s, r1scale=1.0)
 
     def _cross_vec(self, r: _Run, x):
-        """to_out(to_v(ctx)) + b_out for the single context token -> fp32 [B][C]."""
-        c, cross = x["o"].shape[0], x["v"].shape[1]
-        v16 = torch.empty((r.b, c), dtype=torch.float16, device=self.device)
-        ops.gemv(r.ctx16, x["v"], None, n=c, k=cross, rows=r.b, y16=v16)
-        cv = torch.empty((r.b, c), dtype=torch.float32, device=self.device)
-        ops.gemv(v16, x["o"], x["ob"], n=c, k=c, rows=r.b, y32=cv)
-        return cv
+        """to_out(to_v(ctx)) + b_out for the single context token -> fp32 [B][C] (computed by _small_gemvs)."""
+        c, g = x["grp"]
+        return r.cross[c][g]
 
     def _self_attn(self, r: _Run, att, xvec, n_in, resid, *, temporal: bool, **epi):
         c = att["out"].n
@@ -315,12 +365,7 @@ class SVDUNetHIP:
         hs_s = self._gemm(r, p["s_ff2"], g, res1=hs1, r1scale=1.0)
         del g
         # --- frame positional embedding (B*F rows)
-        sin = torch.empty((r.f, c), dtype=torch.float16, device=self.device)
-        ops.sinusoid(r.frame_ids, sin, r.f, c)
-        pe_h = torch.empty((r.f, 4 * c), dtype=torch.float16, device=self.device)
-        ops.gemv(sin, p["pe1"].w, p["pe1"].bias, n=4 * c, k=c, rows=r.f, y16=pe_h, silu_out=True)
-        pe = torch.empty((r.f, c), dtype=torch.float16, device=self.device)
-        ops.gemv(pe_h, p["pe2"].w, p["pe2"].bias, n=c, k=4 * c, rows=r.f, y16=pe)
+        pe = r.pos[c][p["pos_idx"]]
         if r.b > 1:
             pe = pe.repeat(r.b, 1)
         # --- temporal block on hmix = hs_s + pe[frame]
@@ -371,6 +416,7 @@ class SVDUNetHIP:
 
         r = _Run(b=b, f=frames, h=h, w=w, temb=temb, ctx16=ctx16, gn_ws=gn_ws,
                  frame_ids=torch.arange(frames, dtype=torch.float32, device=dev))
+        self._small_gemvs(r)
 
         geom, _, _ = self._conv_geom(r)
         x = self._gemm(r, self.conv_in, x_rows, conv=geom)
