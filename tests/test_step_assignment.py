@@ -89,3 +89,31 @@ def test_rotating_split_extension():
         assign_steps_rotating(25, 8, 0, -1)
     with pytest.raises(ValueError):
         assign_steps_rotating(3, 4, 0, 0)
+
+
+# ---- ring schedule index arithmetic (PipelineConfig.ring) ----------------------------------------------------------
+def test_ring_schedule_properties():
+    """For every world size / sample count: each sample visits ranks home, home+1, ... once per stage, in stage order;
+    in every slot the ranks work on DIFFERENT samples (all at the same stage index); the sender/receiver formulas of a
+    slot boundary agree; and the finishing rank is the one the collection step expects."""
+    from vdpp_amd.pipeline.step_assignment import ring_finish_rank, ring_rank, ring_sample
+    for n in (1, 2, 3, 4, 8):
+        for num in (1, n - 1 or 1, n, n + 1, 2 * n, 3 * n + 2):
+            nbatch = -(-num // n)
+            seen = {}                                     # sample -> list of (slot, rank)
+            for b in range(nbatch):
+                for s in range(n):
+                    here = [ring_sample(r, b, s, n) for r in range(n)]
+                    assert sorted(here) == list(range(b * n, b * n + n))          # a permutation of the batch
+                    for r, i in enumerate(here):
+                        if i < num:
+                            seen.setdefault(i, []).append((s, r))
+                            assert ring_rank(i, s, n) == r
+                        # what rank r sends after slot s is what rank r+1 expects in slot s+1
+                        if s < n - 1:
+                            assert ring_sample((r + 1) % n, b, s + 1, n) == i
+            assert sorted(seen) == list(range(num))
+            for i, visits in seen.items():
+                assert [s for s, _ in visits] == list(range(n))                    # stages 0..N-1 in order
+                assert [r for _, r in visits] == [(i + s) % n for s in range(n)]   # one rank further per stage
+                assert visits[-1][1] == ring_finish_rank(i, n)

@@ -51,7 +51,8 @@ from typing import Callable, Deque, Optional
 import torch
 import torch.distributed as dist
 
-from .step_assignment import StepRange, assign_steps, assign_steps_balanced, assign_steps_rotating, stage_sizes
+from .step_assignment import (StepRange, assign_steps, assign_steps_balanced, assign_steps_rotating, ring_finish_rank,
+                              ring_sample, stage_sizes)
 
 LOGGER = logging.getLogger(__name__)
 
@@ -413,7 +414,7 @@ class PipelineStage:
                 for j in lanes:
                     self._streams[j].wait_stream(main)
             for s in range(n):
-                vid = {j: (g0 + j) * n + ((r - s) % n) for j in lanes}
+                vid = {j: ring_sample(r, g0 + j, s, n) for j in lanes}
                 live = [j for j in lanes if vid[j] < num_samples]
                 if s == 0:
                     for j in live:
@@ -433,7 +434,7 @@ class PipelineStage:
                             with on(j):
                                 self.sample_done_hook(vid[j])
                     continue
-                incoming = [j for j in lanes if (g0 + j) * n + ((r - s - 1) % n) < num_samples]
+                incoming = [j for j in lanes if ring_sample(r, g0 + j, s + 1, n) < num_samples]
                 got = exchange([(j, cur[j]) for j in live], incoming)
                 cur = got
             self._log(f"ring batches {g0}..{g0 + len(lanes) - 1} issued")
@@ -448,7 +449,7 @@ class PipelineStage:
         ops, out = [], {}
         if r == last:
             for i in range(num_samples):
-                src = ((i % n) - 1) % n
+                src = ring_finish_rank(i, n)
                 if src == last:
                     out[i] = finished[i]
                 else:

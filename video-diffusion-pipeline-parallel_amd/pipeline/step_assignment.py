@@ -114,3 +114,20 @@ def stage_sizes(total_steps: int, world_size: int, *, balanced: bool = False) ->
 
     fn = assign_steps_balanced if balanced else assign_steps
     return [fn(total_steps, world_size, r).count for r in range(world_size)]
+
+
+# ---- ring schedule (PipelineConfig.ring): pure index arithmetic, shared by the executor and its tests -------------
+def ring_sample(rank: int, batch: int, slot: int, world_size: int) -> int:
+    """Sample that ``rank`` works on in ``slot`` of ``batch`` (it started on rank ``(rank - slot) mod N``)."""
+
+    return batch * world_size + ((rank - slot) % world_size)
+
+
+def ring_rank(sample_idx: int, stage: int, world_size: int) -> int:
+    """Rank that runs ``stage`` of ``sample_idx``: home rank ``i mod N`` for stage 0, then one rank further per stage."""
+
+    return (sample_idx + stage) % world_size
+
+
+def ring_finish_rank(sample_idx: int, world_size: int) -> int:
+    return ring_rank(sample_idx, world_size - 1, world_size)
