@@ -39,7 +39,11 @@ void sp_set_error(const char *fmt, ...);
     }                                                                     \
   } while (0)
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// SiLU with v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 VALU ops): the GroupNorm apply pass runs it on
+// every element and is otherwise HBM-bound; the result is rounded to fp16 anyway.
+__device__ __forceinline__ float silu_f(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
 // exact-form (erf) GELU, as torch F.gelu(approximate="none"), written for the GEGLU GEMM epilogue where it is the
 // dominant VALU cost: gelu(g) = g*Phi(g) = max(g,0) - |g|*(1 - Phi(|g|)) = g/2 + |g|*(1/2 - (1 - Phi(|g|))) and
 // 1 - Phi(t) = exp2(q(t)) with q a
