@@ -120,6 +120,62 @@ def test_gloo_ring_schedule_equals_plain_loop(golden_dir, ws, num_samples):
         assert torch.equal(got, lat), f"sample {i}"
 
 
+def _sched_worker(rank, ws, golden_dir, init_file, out_file, num_samples, total_steps, mode, conc):
+    torch.set_num_threads(1)
+    z, model = _load(golden_dir, "dummy_c4h64.npz", 4, 64)
+    init_distributed(backend="gloo", rank=rank, world_size=ws, init_method=f"file://{init_file}")
+    x = torch.from_numpy(z["input"])[:1, :, :2, :4, :6].contiguous()      # tiny latent: the test is about index arithmetic
+    ts = list(reversed(range(total_steps)))
+    spec = LatentSpec(shape=x.shape, dtype=torch.float32, device=torch.device("cpu"))
+    quiet = logging.getLogger("quiet"); quiet.setLevel(logging.ERROR)
+    cfg = PipelineConfig(total_steps=total_steps, world_size=ws, rank=rank, timesteps=ts, latent_spec=spec, balanced=True,
+                         ring=mode == "ring", rotate=mode == "rotate", concurrent_samples=conc)
+    stage = PipelineStage(model, cfg, logger=quiet)
+    supplier = (lambda i: x * (1.0 + 0.25 * i)) if (mode == "ring" or rank == 0) else None
+    with torch.no_grad():
+        outs = stage.run_many(num_samples, input_supplier=supplier)
+    if rank == ws - 1:
+        torch.save(outs, out_file)
+    else:
+        assert outs is None
+    finalize_distributed()
+
+
+@pytest.mark.parametrize("ws,num_samples,total_steps,mode,conc", [
+    (5, 13, 25, "ring", 2),      # 3 batches on 2 lanes: the last group runs one lane only
+    (6, 14, 25, "ring", 2),      # the N = 6 rehearsal that printed nothing in round 1 (3 batches, 2 lanes, ragged last batch)
+    (6, 54, 25, "ring", 2),      # its real size: 48 + 6 videos
+    (8, 32, 25, "ring", 2),      # BASELINE config 4 at its real sizes: 8 ranks, 25 steps [4,3,3,3,3,3,3,3], 32 samples
+    (8, 20, 25, "ring", 3),      # 3 batches on 3 lanes, ragged
+    (8, 32, 25, "chain", 1),     # config 4 through the reference's chain (fixed balanced split)
+    (8, 32, 25, "rotate", 1),    # ... and with the extra step rotating over the stages
+    (8, 32, 30, "chain", 1),     # config 5's split: 30 steps on 8 ranks [4,4,4,4,4,4,3,3]
+])
+def test_gloo_schedules_at_real_sizes_equal_plain_loop(golden_dir, ws, num_samples, total_steps, mode, conc):
+    """Chain / rotating chain / ring over Gloo at the world sizes and sample counts of BASELINE configs 3-5
+    (ref src/pipeline/pipeline.py:113-157): every sample equals the plain loop over steps T-1..0, bit for bit, in
+    order, on the last rank.  Sample counts are chosen so that batches do not fill the interleave lanes evenly."""
+    with tempfile.TemporaryDirectory() as td:
+        out_file = os.path.join(td, "out.pt")
+        mp.spawn(_sched_worker, args=(ws, golden_dir, os.path.join(td, "init"), out_file, num_samples, total_steps, mode,
+                                      conc), nprocs=ws, join=True)
+        outs = torch.load(out_file)
+    z, model = _load(golden_dir, "dummy_c4h64.npz", 4, 64)
+    x = torch.from_numpy(z["input"])[:1, :, :2, :4, :6].contiguous()
+    assert len(outs) == num_samples
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)        # as in the workers: the convolution's summation order depends on the thread count
+    try:
+        for i, got in enumerate(outs):
+            lat = x * (1.0 + 0.25 * i)
+            with torch.no_grad():
+                for s in reversed(range(total_steps)):
+                    lat = model(lat, s)
+            assert torch.equal(got, lat), f"sample {i}"
+    finally:
+        torch.set_num_threads(threads)
+
+
 def test_ring_schedule_requires_supplier_everywhere():
     spec = LatentSpec(shape=torch.Size((1, 4, 2, 4, 4)), dtype=torch.float32, device=torch.device("cpu"))
     stage = PipelineStage(lambda l, s: l, PipelineConfig(total_steps=4, world_size=2, rank=1, timesteps=[3, 2, 1, 0],

@@ -375,7 +375,8 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   SP_REQUIRE(d->ldd % 8 == 0 || d->n_store > 0, "sp_gemm_f16: ldd must be a multiple of 8");
   GemmArgs a{};
 #ifdef SP_GEMM_EXPERIMENTS
-  { const char *e = getenv("SP_GEMM_DBG"); a.dbg = e ? atoi(e) : 0; }   // ablation builds only (make EXTRA=-DSP_GEMM_EXPERIMENTS)
+  { const char *e = getenv("SP_GEMM_DBG"); a.dbg = e ? atoi(e) : 0; }   // ablation builds only (make exp)
+  { const char *e = getenv("SP_GEMM_STAGGER"); a.stagger = e ? atoi(e) : 0; }
 #endif
   a.a = (const f16 *)d->a; a.w = (const f16 *)d->w; a.bias = d->bias; a.bias2 = d->bias2;
   a.res1 = (const f16 *)d->res1; a.res2 = (const f16 *)d->res2; a.d = (f16 *)d->d;

@@ -29,6 +29,7 @@ struct GemmArgs {
   int geglu, n_store;
   int tiles_m, tiles_n;
   int dbg;   // ablation builds only (-DSP_GEMM_EXPERIMENTS + SP_GEMM_DBG): selects gemm_pp_kernel<.., EXP>
+  int stagger;   // ablation builds only (SP_GEMM_STAGGER): first-round workgroups start (b/8 & 3) * stagger us late
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -242,6 +242,14 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const bool late = NWV == 8 && wave >= 4;
+#ifdef SP_GEMM_EXPERIMENTS
+  // lock-step experiment: the first round of workgroups (one per CU) starts in four phase groups, so that later
+  // rounds keep prologue reads / K loops / epilogue stores of neighbouring CUs apart in time
+  if (p.stagger > 0 && blockIdx.x < 256) {
+    const int d = ((blockIdx.x >> 3) & 3) * p.stagger;
+    for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(30);   // 30 * 64 cycles ~ 1 us at 1.9 GHz
+  }
+#endif
   PP_TRACE(0);
 #ifdef SP_GEMM_EXPERIMENTS
   if (tid == 0 && blockIdx.x < PP_TRACE_WGS) {

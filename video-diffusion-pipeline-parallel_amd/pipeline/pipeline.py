@@ -345,7 +345,10 @@ class PipelineStage:
         ``(rank - s) mod N``, then hands it to rank+1 and receives its slot ``s+1`` sample from rank-1, both in ONE
         ``batch_isend_irecv`` (a grouped RCCL call: safe on a ring, also for N = 2 where both neighbours are the same
         peer).  In every slot all ranks run the same stage index, so slots line up and nobody waits for a pipeline to
-        fill or drain.  ``concurrent_samples`` batches are interleaved on separate HIP streams.  Finished latents are
+        fill or drain.  ``concurrent_samples`` batches are interleaved on separate HIP streams: their kernels share
+        the GPU, but the exchange is bulk-synchronous per slot (ONE grouped exchange for all lanes, ordered behind
+        every lane's last step of the slot), so a lane does not overlap its own hand-off with its own compute; the
+        1-2 MB hand-off is microseconds on xGMI against >= 150 ms of stage compute.  Finished latents are
         collected on the last rank at the end (same return contract as the chain: list on the last rank, ``None``
         elsewhere).  Every rank needs the ``input_supplier`` (it produces the inputs of its home samples)."""
 
@@ -358,7 +361,9 @@ class PipelineStage:
         sizes = stage_sizes(cfg.total_steps, n, balanced=True)
         starts = [sum(sizes[:j]) for j in range(n)]
         nxt_rank, prv_rank = (r + 1) % n, (r - 1) % n
-        conc = max(1, cfg.concurrent_samples) if cuda else 1
+        # interleave lanes: one HIP stream each on a GPU rank; on a CPU/Gloo rank they are plain bookkeeping (same
+        # exchange pattern, so the lane logic is covered by the world_size 5/6/8 Gloo tests)
+        conc = max(1, cfg.concurrent_samples)
         nbatch = (num_samples + n - 1) // n
         if cuda:
             if not hasattr(self, "_streams") or len(self._streams) < conc:
