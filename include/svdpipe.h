@@ -82,6 +82,13 @@ typedef struct sp_gemm_desc {
 
 int sp_gemm_f16(const sp_gemm_desc *desc, void *stream);
 
+/* Test / micro-benchmark hook (no counterpart in the reference): pins the kernel family sp_gemm_f16 picks for the
+ * shapes that family supports; everything else keeps the automatic choice.  Process-wide, not thread-safe: set it
+ * before the calls it should affect.  route 0 = automatic (default), 1 = small tiles only, 2 = ping-pong large tiles
+ * (bm in {0,128,192,256}, bn in {0,256,320}; 0 = automatic), 3 = persistent-stream tiles (bm in {0,192,256},
+ * bn in {0,256}). */
+int sp_gemm_set_route(int route, int bm, int bn);
+
 /* y[n] = act_out( W[n][:] . act_in(x) + b[n] ), M = 1.  Replaces the nn.Linear GEMVs of the
  * timestep / added-time / frame-position embeddings and every `time_emb_proj` (diffusers
  * TimestepEmbedding, ResnetBlock2D.time_emb_proj).  x, W fp16; b, y fp32 (y_f16 optional copy).

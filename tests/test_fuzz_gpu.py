@@ -13,16 +13,16 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
-@pytest.mark.parametrize("force,bm", [(None, None), ("2", "256"), ("2", "192"), ("2", "128"), ("1", None)])
-def test_gemm_fuzz(monkeypatch, force, bm):
+@pytest.mark.parametrize("route,bm", [(0, 0), (2, 256), (2, 192), (2, 128), (1, 0), (3, 256), (3, 192)])
+def test_gemm_fuzz(route, bm):
+    """route: sp_gemm_set_route (0 automatic, 1 small tiles, 2 ping-pong, 3 persistent-stream); route 3 draws long-K,
+    many-row linear shapes more often so that workgroups walk several tiles."""
     import fuzz_gemm
-    if force:
-        monkeypatch.setenv("SP_GEMM_FORCE", force)
-    if bm:
-        monkeypatch.setenv("SP_GEMM_BM", bm)
-    seed = 1000 + int(bm or 0) + int(force or 0)
+    from vdpp_amd.hip import ops
+    seed = 1000 + bm + route
     rng, g = random.Random(seed), torch.Generator().manual_seed(seed)
-    worst = max(fuzz_gemm.one(rng, g) for _ in range(30))
+    with ops.gemm_route(route, bm=bm):
+        worst = max(fuzz_gemm.one(rng, g, stream_shapes=route == 3) for _ in range(30))
     assert worst <= 3e-3
 
 

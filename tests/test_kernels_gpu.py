@@ -58,9 +58,9 @@ def test_gemm_linear(m, n, k):
 
 
 @pytest.fixture(params=[256, 192, 128])
-def force_large_tiles(monkeypatch, request):
-    monkeypatch.setenv("SP_GEMM_FORCE", "2")   # route eligible shapes through gemm_pp.hip (BM x 256 / BM x 320 tiles)
-    monkeypatch.setenv("SP_GEMM_BM", str(request.param))
+def force_large_tiles(request):
+    with _ops().gemm_route(2, bm=request.param):   # eligible shapes through gemm_pp.hip (BM x 256 / BM x 320 tiles)
+        yield
 
 
 @pytest.mark.parametrize("m,n,k", [(1024, 256, 64), (700, 512, 192), (3000, 320, 64), (2049, 960, 192), (5000, 1280, 128)])
@@ -109,6 +109,40 @@ def test_gemm_large_tile_geglu_conv_temporal(force_large_tiles):
     o = torch.empty_like(rows, dtype=torch.float16, device=DEV)
     ops.gemm(rows.half().to(DEV), W.pack_tconv3(wt).to(DEV), o, m=rows.shape[0], n=c, cin=c, mode=ops.A_TEMPORAL3, temporal=(frames, hw), bias=bt.to(DEV))
     check(o.view(1, frames, hw, c).permute(0, 3, 1, 2), ref[..., 0])
+
+
+@pytest.mark.parametrize("bm,m,n,k,geglu", [(256, 32256, 2560, 320, True), (192, 32256, 2560, 320, True),
+                                            (256, 40000, 1280, 320, False), (192, 129024 // 2, 256, 640, False),
+                                            (192, 50001, 960, 320, False), (192, 36000, 320, 1280, False)])
+def test_gemm_persistent_stream_many_tiles(bm, m, n, k, geglu):
+    """gemm_ps.hip with several tiles per workgroup (grid 256, up to 6 tiles each): the LDS-DMA stream crosses tile
+    boundaries, stores of tile i are in flight behind the loads of tile i+1.  bias + bias2 (one row per batch item),
+    two residuals, ragged last row tile; every output row against fp32 torch (2e-3 relative L2)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(m + n + k)
+    a = h(torch.randn(m, k, generator=g)); w = h(torch.randn(n, k, generator=g) / math.sqrt(k))
+    bias = torch.randn(n, generator=g)
+    nout = n // 2 if geglu else n
+    out = torch.full((m + 2, nout), 7.0, dtype=torch.float16, device=DEV)
+    kw = dict(m=m, n=n, cin=k, bias=bias.to(DEV), geglu=geglu)
+    y = a @ w.t() + bias
+    if geglu:
+        wi, bi = _w().interleave_geglu(w, bias)
+        kw.update(bias=bi.to(DEV))
+        y = y[:, :nout] * F.gelu(y[:, nout:])
+        wdev = wi.half().to(DEV)
+    else:
+        b2 = torch.randn(1, n, generator=g)
+        res = h(torch.randn(m, n, generator=g)); res2 = h(torch.randn(m, n, generator=g))
+        kw.update(bias2=b2.to(DEV), bias2_rows=m, res1=res.half().to(DEV), r1scale=0.5, res2=res2.half().to(DEV),
+                  r2scale=-0.25, oscale=2.0)
+        y = 2.0 * (y + b2) + 0.5 * res - 0.25 * res2
+        wdev = w.half().to(DEV)
+    with ops.gemm_route(3, bm=bm):
+        ops.gemm(a.half().to(DEV), wdev, out[1:m + 1], **kw)
+    torch.cuda.synchronize()
+    assert torch.all(out[0] == 7.0) and torch.all(out[m + 1] == 7.0), "guard rows written"
+    check(out[1:m + 1], y)
 
 
 def test_gemm_two_residuals_bias2_and_nstore():

@@ -159,6 +159,33 @@ def test_adapter_errors_and_api_surface():
         StableVideoUNet.from_pretrained("stabilityai/stable-video-diffusion-img2vid-xt")   # hub id: no network
 
 
+def test_adapter_rejects_conditioning_of_another_shape():
+    """The kernels get raw pointers + the latent's (B, F, H, W): mismatched conditioning must raise, not read out of
+    bounds (the reference fails in torch.cat / on broadcast, svd_unet.py:385-411)."""
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+
+    cfg, sd, ref, hip = _build(seed=10)
+    model = StableVideoUNet(unet=hip, timesteps=StableVideoUNet._default_timestep_schedule(25))
+    dev = torch.device(DEV)
+    model.set_dummy_conditioning(1, 14, 8, 8, dev, guidance_scale=3.0)
+    ok = torch.zeros(1, 4, 14, 8, 8, dtype=torch.float16, device=DEV)
+    assert model(ok, 0).shape == ok.shape
+    for shape in ((1, 4, 25, 8, 8),          # conditioning for 14 frames, latent with 25
+                  (2, 4, 14, 8, 8),          # conditioning batch smaller than the latent batch
+                  (1, 4, 14, 16, 8),         # other spatial size
+                  (1, 8, 14, 8, 8),          # not 4 latent channels
+                  (4, 14, 8, 8)):            # not 5-D
+        with pytest.raises(ValueError):
+            model(torch.zeros(shape, dtype=torch.float16, device=DEV), 0)
+    emb = torch.randn(1, 2, cfg.cross_attention_dim, dtype=torch.float16, device=DEV)     # two context tokens
+    model.set_conditioning(emb, torch.zeros_like(ok), num_frames=14)
+    with pytest.raises(ValueError):
+        model(ok, 0)
+    model.set_conditioning(emb[:, :1], torch.zeros_like(ok), guidance_scale=2.0, num_frames=7)   # guidance for 7 frames
+    with pytest.raises(ValueError):
+        model(ok, 0)
+
+
 def test_pipeline_stage_on_gpu_single_rank_matches_loop():
     """PipelineStage (world_size 1) driving the HIP adapter == calling the adapter in a loop (bit-identical)."""
     from vdpp_amd.models.svd_unet import StableVideoUNet
@@ -222,6 +249,44 @@ def test_graph_replay_equals_eager():
     assert len(graphed._graphs) == 2
     graphed.set_conditioning(emb * 2, img, num_frames=frames)     # invalidates the captured graphs
     assert len(graphed._graphs) == 0
+
+
+def test_graph_replay_with_two_videos_in_flight():
+    """HIP graphs + concurrent_samples = 2 (what bench.py runs with VDPP_GRAPHS=1): every lane has its own graph,
+    static buffers, pool and scratch, so interleaved replays equal the sequential eager results bit for bit."""
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+    from vdpp_amd.pipeline import LatentSpec, PipelineConfig, PipelineStage
+
+    cfg, sd, ref, hip = _build(seed=29)
+    steps = 4
+    ts = StableVideoUNet._default_timestep_schedule(steps)
+    eager = StableVideoUNet(unet=hip, timesteps=ts)
+    graphed = StableVideoUNet(unet=hip, timesteps=ts)
+    graphed.enable_graphs()
+    torch.manual_seed(8)
+    frames, h, w = 3, 16, 16
+    emb = torch.randn(1, 1, cfg.cross_attention_dim).half().to(DEV)
+    img = torch.randn(1, 4, frames, h, w).half().to(DEV)
+    for m in (eager, graphed):
+        m.set_conditioning(emb, img, num_frames=frames)
+    shape = torch.Size((1, 4, frames, h, w))
+    spec = LatentSpec(shape=shape, dtype=torch.float16, device=torch.device(DEV))
+    xs = [(torch.randn(shape) * 20 * (i + 1)).half().to(DEV) for i in range(6)]
+
+    def run(model, conc):
+        stage = PipelineStage(model, PipelineConfig(total_steps=steps, world_size=1, rank=0, timesteps=list(range(steps)),
+                                                    latent_spec=spec, concurrent_samples=conc))
+        out = stage.run_many(len(xs), input_supplier=lambda i: xs[i])
+        torch.cuda.synchronize()
+        return out
+
+    want = run(eager, 1)
+    for trial in range(2):                       # first pass captures (per lane), second pass only replays
+        got = run(graphed, 2)
+        for i, (a, b) in enumerate(zip(want, got)):
+            assert torch.equal(a, b), f"trial {trial} sample {i}"
+    lanes = {k[0] for k in graphed._graphs}
+    assert len(lanes) == 2 and len(graphed._graphs) == 2 * steps       # one graph per (lane, step)
 
 
 def test_interleaved_run_many_equals_sequential():
@@ -446,9 +511,9 @@ def test_benchmark_shape_two_kernel_routes_agree_and_are_deterministic(monkeypat
     b = model(lat, 0)
     assert torch.isfinite(a).all()
     assert torch.equal(a, b), "two launches of the same step differ"
-    monkeypatch.setenv("SP_GEMM_FORCE", "1")          # never use gemm_pp.hip
-    c = model(lat, 0)
-    monkeypatch.delenv("SP_GEMM_FORCE")
+    from vdpp_amd.hip import ops
+    with ops.gemm_route(1):                            # small tiles only: neither gemm_pp.hip nor gemm_ps.hip
+        c = model(lat, 0)
     # compare the UPDATE (new - old latent): the latent itself is dominated by the unchanged sigma*noise term
     upd_a, upd_c = (a.float() - lat.float()).cpu(), (c.float() - lat.float()).cpu()
     err = rel_l2(upd_c, upd_a)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-check of sp_gemm_f16 against fp32 torch (CPU): shapes, modes and epilogue flags drawn at random,
-output rows guarded on both sides (any write outside [0, m) x [0, n_store) fails).  usage: fuzz_gemm.py [cases] [seed]
-Env SP_GEMM_FORCE / SP_GEMM_BM / SP_GEMM_BN select the kernel family as in tests/test_kernels_gpu.py."""
+output rows guarded on both sides (any write outside [0, m) x [0, n_store) fails).
+usage: fuzz_gemm.py [cases] [seed] [route] [bm]   (route / bm: sp_gemm_set_route, as in tests/test_fuzz_gpu.py)"""
 import math, os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,14 +23,18 @@ def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-def one(rng, g):
+def one(rng, g, stream_shapes=False):
     mode = rng.choice([0, 0, 1, 2])
     n = rng.choice([64, 128, 192, 256, 320, 512, 640, 960, 1280])
     cin = rng.choice([64, 128, 192, 320])
+    if stream_shapes and rng.random() < 0.7:          # what gemm_ps.hip takes: linear, K >= 256, N % 256 or % 320
+        mode, n, cin = 0, rng.choice([256, 320, 512, 640, 960, 1280, 2560]), rng.choice([320, 640, 1280])
     geglu = mode == 0 and n % 128 == 0 and rng.random() < 0.3
     kw = {}
     if mode == 0:
         m = rng.choice([1, 7, 64, 255, 256, 257, 1000, 2560, 2561, 2700, 3000, 4097, 6001])
+        if stream_shapes and rng.random() < 0.5:
+            m = rng.choice([12000, 20001, 33000, 48000])     # several tiles per workgroup of a 256-workgroup grid
         a = h(torch.randn(m, cin, generator=g))
         wt = h(torch.randn(n, cin, generator=g) / math.sqrt(cin))
         y = a @ wt.t()
@@ -112,15 +116,17 @@ def one(rng, g):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    route = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    bm = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     rng = random.Random(seed)
     g = torch.Generator().manual_seed(seed)
     worst = 0.0
-    for i in range(cases):
-        worst = max(worst, one(rng, g))
-        if (i + 1) % 25 == 0:
-            print(f"{i + 1} cases ok, worst rel_l2 {worst:.2e}", flush=True)
-    print(f"fuzz_gemm: {cases} cases passed (seed {seed}, FORCE={os.environ.get('SP_GEMM_FORCE')}, BM={os.environ.get('SP_GEMM_BM')}), "
-          f"worst rel_l2 {worst:.2e}")
+    with ops.gemm_route(route, bm=bm):
+        for i in range(cases):
+            worst = max(worst, one(rng, g, stream_shapes=route == 3))
+            if (i + 1) % 25 == 0:
+                print(f"{i + 1} cases ok, worst rel_l2 {worst:.2e}", flush=True)
+    print(f"fuzz_gemm: {cases} cases passed (seed {seed}, route {route}, bm {bm}), worst rel_l2 {worst:.2e}")
 
 
 if __name__ == "__main__":

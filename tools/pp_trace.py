@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase breakdown of the ping-pong GEMM per workgroup (needs `make EXTRA=-DSP_GEMM_EXPERIMENTS`).
+"""Phase breakdown of the ping-pong GEMM per workgroup (needs `make -C csrc exp`: loads libsvdpipe_hip_exp.so).
 
 Each workgroup records a 100 MHz wall-clock stamp at entry, after the prologue, after the K loop and after the
 epilogue, plus its hardware id; this prints the mean of each phase and the idle gap between consecutive
@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import vdpp_amd  # noqa
 from vdpp_amd import hip
+hip.LIB_PATH = os.path.join(os.path.dirname(hip.LIB_PATH), "libsvdpipe_hip_exp.so")
 from vdpp_amd.hip import ops
 
 
@@ -38,6 +39,8 @@ def run(spec):
     kw = dict(m=m, n=n, cin=cin, mode=mode, conv=conv, temporal=temporal, bias=bias, geglu=geglu)
     if resid:
         kw["res1"] = torch.randn(m, no, device=dev, dtype=torch.float16)
+    bm = int(os.environ.get("BM", 256))
+    hip.load().sp_gemm_set_route(2, bm, 0)          # the stamps live in gemm_pp.hip
     for _ in range(3): ops.gemm(a, wt, out, **kw)
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -49,7 +52,6 @@ def run(spec):
     buf = np.zeros((nw, 12), dtype=np.int64)
     rc = lib.sp_debug_pp_trace(buf.ctypes.data_as(ctypes.c_void_p), nw)
     assert rc == 0, rc
-    bm = int(os.environ.get("SP_GEMM_BM", 256))
     used = buf[:, 0] > 0
     # only the workgroups of this launch: stamps within the last launch window
     tmax = buf[used, 3].max()

@@ -18,6 +18,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void sp_set_error(const char *fmt, ...);
 
+constexpr int SP_MAX_DEVICES = 64;
+int sp_ensure_dyn_lds(const void *kernel, int bytes, bool (&done)[SP_MAX_DEVICES], const char *name);
+
 #define SP_REQUIRE(cond, ...)                 \
   do {                                        \
     if (!(cond)) {                            \
@@ -61,6 +64,22 @@ __device__ __forceinline__ float gelu_f(float v) {
   q = fmaf(q, a, -9.999913501e-01f);
   // max(v,0) - |v|*e  ==  0.5*v + |v|*(0.5 - e): three VALU ops, no compare/select and no canonicalising max
   return fmaf(fabsf(v), 0.5f - __builtin_amdgcn_exp2f(q), 0.5f * v);
+}
+
+// Two GELUs at once on packed-fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of fp32 per VALU issue);
+// same polynomial, same rounding as gelu_f.  The GEGLU epilogues are VALU-bound, the fma chain is 60 % of their work.
+__device__ __forceinline__ f32x2 gelu2_f(f32x2 v) {
+  const f32x2 av = {fabsf(v[0]), fabsf(v[1])};
+  const f32x2 a = {__builtin_amdgcn_fmed3f(av[0], 0.0f, 5.6f), __builtin_amdgcn_fmed3f(av[1], 0.0f, 5.6f)};
+  f32x2 q = {3.470272457e-05f, 3.470272457e-05f};
+  q = __builtin_elementwise_fma(q, a, (f32x2){-7.831060430e-04f, -7.831060430e-04f});
+  q = __builtin_elementwise_fma(q, a, (f32x2){8.125715224e-03f, 8.125715224e-03f});
+  q = __builtin_elementwise_fma(q, a, (f32x2){-5.348086292e-02f, -5.348086292e-02f});
+  q = __builtin_elementwise_fma(q, a, (f32x2){-4.587201634e-01f, -4.587201634e-01f});
+  q = __builtin_elementwise_fma(q, a, (f32x2){-1.151218199e+00f, -1.151218199e+00f});
+  q = __builtin_elementwise_fma(q, a, (f32x2){-9.999913501e-01f, -9.999913501e-01f});
+  const f32x2 e = {0.5f - __builtin_amdgcn_exp2f(q[0]), 0.5f - __builtin_amdgcn_exp2f(q[1])};
+  return __builtin_elementwise_fma(av, e, v * 0.5f);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -347,12 +347,9 @@ template <int BM, int BN, int WM, int WN, int STAGES>
 int launch(GemmArgs &a, hipStream_t s) {
   constexpr size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
   static_assert((size_t)BM * (BN + 8) * 2 <= lds, "epilogue staging tile must fit in the ring");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)gemm_f16_kernel<BM, BN, WM, WN, STAGES>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static bool attr_set[SP_MAX_DEVICES] = {};
+  if (int rc = sp_ensure_dyn_lds((const void *)gemm_f16_kernel<BM, BN, WM, WN, STAGES>, (int)lds, attr_set, "sp_gemm_f16"))
+    return rc;
   a.tiles_m = (a.m + BM - 1) / BM;
   a.tiles_n = a.n / BN;
   SP_CLEAR_STALE_ERROR();
@@ -363,6 +360,87 @@ int launch(GemmArgs &a, hipStream_t s) {
 }
 
 }  // namespace
+
+namespace {
+
+// Kernel-family override for tests and micro-benchmarks (sp_gemm_set_route); 0 = automatic everywhere.
+int g_route = 0, g_route_bm = 0, g_route_bn = 0;
+
+// ceil(tiles / 256 CUs) rounds of bm x bn tiles: the busiest CU's share of the output
+double makespan(int m, int n, int bm, int bn) {
+  const int tiles = ((m + bm - 1) / bm) * (n / bn);
+  return (double)((tiles + 255) / 256) * bm * bn;
+}
+
+int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
+  const bool n128 = d->n % 128 == 0;
+  const bool ok256 = d->n % 256 == 0, ok320 = d->n % 320 == 0 && !d->geglu;
+  const int route = g_route;
+
+  // ---- persistent-stream tiles (gemm_ps.hip): linear contractions with several tiles per CU, where launch gap,
+  // index setup, first-operand latency and the LDS-staged epilogue of a one-tile workgroup are a large share
+  if ((route == 0 || route == 3) && ok256) {
+    int bm = 0, bn = 0;
+    double best = 0.0;
+    const int cand[2][2] = {{256, 256}, {192, 256}};
+    for (int c = 0; c < 2; ++c) {
+      const int cbm = cand[c][0], cbn = cand[c][1];
+      if ((cbn == 256 && !ok256) || (cbn == 320 && !ok320)) continue;
+      if (route == 3 && ((g_route_bm && g_route_bm != cbm) || (g_route_bn && g_route_bn != cbn))) continue;
+      a.tiles_m = (d->m + cbm - 1) / cbm;
+      a.tiles_n = d->n / cbn;
+      if (!spgemm::ps_supported(a, cbm, cbn)) continue;
+      double t = makespan(d->m, d->n, cbm, cbn);
+      if (cbm == 192) t *= 1.10;            // smaller tiles move more operand bytes per FLOP (measured 8-10 %)
+      if (!bm || t < best) { best = t; bm = cbm; bn = cbn; }
+    }
+    if (bm) {
+      const int tiles = ((d->m + bm - 1) / bm) * (d->n / bn);
+      if (route == 3 || tiles >= 448) return launch_ps(a, bm, bn, s);
+    }
+  }
+
+  if (d->m <= 2560 && route != 2) {   // few rows (the 2016-row level): small tiles so the grid still covers 256 CUs
+    if (d->n >= 3840 && n128) return launch<128, 128, 2, 2, 2>(a, s);
+    return launch<64, 64, 2, 2, 3>(a, s);
+  }
+  // ---- large ping-pong tiles (gemm_pp.hip) for every N that is a multiple of 256 or 320
+  if (route != 1 && (ok256 || ok320)) {
+    // Pick the (BM, BN) whose last round of workgroups wastes the fewest of the 256 CUs (one workgroup per CU);
+    // larger tiles win ties because they move fewer operand bytes per FLOP.
+    int bm = 256, bn = ok256 ? 256 : 320;
+    double best = -1.0;
+    const int bms[2] = {256, 192}, bns[2] = {256, 320};
+    for (int bi = 0; bi < 2; ++bi)
+      for (int ni = 0; ni < 2; ++ni) {
+        if ((bns[ni] == 256 && !ok256) || (bns[ni] == 320 && !ok320)) continue;
+        const int blocks = ((d->m + bms[bi] - 1) / bms[bi]) * (d->n / bns[ni]);
+        double score = (double)blocks / (((blocks + 255) / 256) * 256.0);
+        if (bms[bi] == 192) score -= 0.06;
+        if (bns[ni] == 320) score -= 0.01;
+        if (score > best) { best = score; bm = bms[bi]; bn = bns[ni]; }
+      }
+    if (route == 2) {
+      if ((g_route_bn == 256 && ok256) || (g_route_bn == 320 && ok320)) bn = g_route_bn;
+      if (g_route_bm == 192 || g_route_bm == 256 || (g_route_bm == 128 && bn == 256)) bm = g_route_bm;
+    }
+    return launch_pp(a, bm, bn, s);
+  }
+  if (n128 && d->m >= 4096) return launch<256, 128, 4, 2, 3>(a, s);
+  if (n128) return launch<128, 128, 2, 2, 2>(a, s);
+  if (d->n % 160 == 0) return launch<128, 160, 2, 2, 2>(a, s);
+  return launch<128, 64, 2, 2, 2>(a, s);
+}
+
+}  // namespace
+
+extern "C" int sp_gemm_set_route(int route, int bm, int bn) {
+  SP_REQUIRE(route >= 0 && route <= 3, "sp_gemm_set_route: route %d (0 auto, 1 small tiles, 2 ping-pong, 3 persistent-stream)", route);
+  SP_REQUIRE(bm == 0 || bm == 128 || bm == 192 || bm == 256, "sp_gemm_set_route: bm %d", bm);
+  SP_REQUIRE(bn == 0 || bn == 256 || bn == 320, "sp_gemm_set_route: bn %d", bn);
+  g_route = route; g_route_bm = bm; g_route_bn = bn;
+  return SP_OK;
+}
 
 extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   SP_REQUIRE(d != nullptr, "sp_gemm_f16: null descriptor");
@@ -410,41 +488,5 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   }
   if (d->geglu) SP_REQUIRE(d->n % 128 == 0, "sp_gemm_f16: geglu needs n %% 128 == 0");
   hipStream_t s = (hipStream_t)stream;
-  const bool n128 = d->n % 128 == 0;
-  if (d->m <= 2560) {   // few rows (the 2016-row level): small tiles so the grid still covers 256 CUs
-    if (d->n >= 3840 && n128) return launch<128, 128, 2, 2, 2>(a, s);
-    return launch<64, 64, 2, 2, 3>(a, s);
-  }
-  {
-    // large ping-pong tiles (gemm_pp.hip) for every N that is a multiple of 256 or 320
-    const char *fe = getenv("SP_GEMM_FORCE");   // experiments/tests: 1 = never, 2 = always use the large tiles
-    const int force = fe ? atoi(fe) : 0;
-    const char *be = getenv("SP_GEMM_BN");      // experiments: force 256 or 320
-    const int tm = (d->m + 255) / 256;
-    const bool ok256 = d->n % 256 == 0, ok320 = d->n % 320 == 0 && !d->geglu;
-    if (force != 1 && (ok256 || ok320)) {
-      // Pick the (BM, BN) whose last round of workgroups wastes the fewest of the 256 CUs (one workgroup per CU);
-      // larger tiles win ties because they move fewer operand bytes per FLOP.
-      int bm = 256, bn = ok256 ? 256 : 320;
-      double best = -1.0;
-      const int bms[2] = {256, 192}, bns[2] = {256, 320};
-      for (int bi = 0; bi < 2; ++bi)
-        for (int ni = 0; ni < 2; ++ni) {
-          if ((bns[ni] == 256 && !ok256) || (bns[ni] == 320 && !ok320)) continue;
-          const int blocks = ((d->m + bms[bi] - 1) / bms[bi]) * (d->n / bns[ni]);
-          double score = (double)blocks / (((blocks + 255) / 256) * 256.0);
-          if (bms[bi] == 192) score -= 0.06;
-          if (bns[ni] == 320) score -= 0.01;
-          if (score > best) { best = score; bm = bms[bi]; bn = bns[ni]; }
-        }
-      if (be) { const int want = atoi(be); if ((want == 256 && ok256) || (want == 320 && ok320)) bn = want; }
-      const char *me = getenv("SP_GEMM_BM");    // experiments/tests: force 128 / 192 / 256
-      if (me) { const int want = atoi(me); if (want == 192 || want == 256 || (want == 128 && bn == 256)) bm = want; }
-      return launch_pp(a, bm, bn, s);
-    }
-  }
-  if (n128 && d->m >= 4096) return launch<256, 128, 4, 2, 3>(a, s);
-  if (n128) return launch<128, 128, 2, 2, 2>(a, s);
-  if (d->n % 160 == 0) return launch<128, 160, 2, 2, 2>(a, s);
-  return launch<128, 64, 2, 2, 2>(a, s);
+  return dispatch(a, d, s);
 }

@@ -44,4 +44,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // ping-pong large-tile kernels (gemm_pp.hip): bm in {128 (bn 256 only), 192, 256}, bn in {256, 320}
 int launch_pp(GemmArgs &a, int bm, int bn, hipStream_t s);
 
+// persistent-stream kernels (gemm_ps.hip): (bm, bn) in {(256,256), (192,256)}; see ps_supported
+bool ps_supported(const GemmArgs &a, int bm, int bn);
+int launch_ps(GemmArgs &a, int bm, int bn, hipStream_t s);
+
 }  // namespace spgemm

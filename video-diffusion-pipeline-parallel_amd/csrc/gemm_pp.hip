@@ -112,8 +112,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
         o = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
       } else {
         const f32x4 h = acc[2 * i][j] * p.oscale, g = acc[2 * i + 1][j];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (f16)(h[r] * gelu_f(g[r]));
+        const f32x2 ga = gelu2_f((f32x2){g[0], g[1]}), gb = gelu2_f((f32x2){g[2], g[3]});
+        o = (f16x4){(f16)(h[0] * ga[0]), (f16)(h[1] * ga[1]), (f16)(h[2] * gb[0]), (f16)(h[3] * gb[1])};
       }
       const int row = wm * WTM + j * 16 + fr;
       *(f16x4 *)(smem + row * (bno * 2) + ((((col >> 3) ^ (fr & 7))) << 4) + (col & 4) * 2) = o;
@@ -522,12 +522,9 @@ int launch_pp(GemmArgs &a, hipStream_t s) {
   constexpr size_t ring = (size_t)NSTG * (BM + BN) * 64, tile = (size_t)BM * BN * 2;   // epilogue stages the fp16 tile
   constexpr size_t lds = ring > tile ? ring : tile;
   static_assert(lds <= 160 * 1024, "LDS per workgroup");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)gemm_pp_kernel<BM, BN, EXP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
+  static bool attr_set[SP_MAX_DEVICES] = {};
+  if (int rc = sp_ensure_dyn_lds((const void *)gemm_pp_kernel<BM, BN, EXP>, (int)lds, attr_set, "sp_gemm_f16(pp)"))
+    return rc;
   a.tiles_m = (a.m + BM - 1) / BM;
   a.tiles_n = a.n / BN;
   SP_CLEAR_STALE_ERROR();

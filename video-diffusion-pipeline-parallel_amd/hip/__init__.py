@@ -38,6 +38,7 @@ SIGNATURES = {
     "sp_last_error": (ctypes.c_char_p, []),
     "sp_version": (_I, []),
     "sp_gemm_f16": (_I, [ctypes.POINTER(GemmDesc), _P]),
+    "sp_gemm_set_route": (_I, [_I, _I, _I]),
     "sp_gemv_f16": (_I, [_P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "sp_gemv_batched_f16": (_I, [_P, _L, _L, _P, _L, _P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P]),
     "sp_sinusoid_f16": (_I, [_P, _P, _I, _I, _P]),

@@ -105,6 +105,22 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
     return out
 
 
+class gemm_route:
+    """``with gemm_route(3, bm=256): ...`` pins the kernel family of ``sp_gemm_f16`` (tests / micro-benchmarks only;
+    see ``sp_gemm_set_route`` in include/svdpipe.h): 1 small tiles, 2 ping-pong, 3 persistent-stream."""
+
+    def __init__(self, route: int, bm: int = 0, bn: int = 0):
+        self.args = (route, bm, bn)
+
+    def __enter__(self):
+        _check(load().sp_gemm_set_route(*self.args), "sp_gemm_set_route")
+        return self
+
+    def __exit__(self, *exc):
+        load().sp_gemm_set_route(0, 0, 0)
+        return False
+
+
 def gemv(x, w, b, *, n, k, rows=1, ldx=None, y32=None, y16=None, ldy=None, silu_in=False, silu_out=False):
     _check(load().sp_gemv_f16(_f16(x, "x").data_ptr(), int(ldx if ldx is not None else k), _f16(w, "w").data_ptr(),
                               _ptr(b), _ptr(y32), _ptr(y16), int(ldy if ldy is not None else n), rows, n, k,

@@ -44,8 +44,8 @@ class StableVideoUNet(nn.Module):
         super().__init__()
         self.batched_cfg = batched_cfg
         self._use_graphs = os.environ.get("VDPP_GRAPHS", "0") == "1"
-        self._graphs: dict = {}
-        self._graph_pool = None
+        self._graphs: dict = {}          # (calling stream, step, latent shape) -> (graph, static_in, static_out)
+        self._graph_lanes: dict = {}     # calling stream -> (capture stream, memory pool) of that lane
         if dtype != torch.float16:
             raise ValueError("the MI355X SVD path computes in float16 (fp32 accumulate)")
         if not isinstance(unet, SVDUNetHIP):
@@ -66,6 +66,7 @@ class StableVideoUNet(nn.Module):
         self._uncond_embeddings = None
         self._uncond_image_latents = None
         self._guidance_scale_tensor = None
+        self._guidance32 = None
 
     # ------------------------------------------------------------------ schedule
     def _init_scheduler(self) -> None:
@@ -161,10 +162,13 @@ class StableVideoUNet(nn.Module):
 
         A step is ~1,100 kernel launches issued from Python; the graph removes that host work from the critical path
         (it matters when the host is slow or the latent is small; at the benchmark shape the GPU is the bottleneck
-        either way).  Graphs share one memory pool; conditioning changes invalidate them."""
+        either way).  Graphs, their static buffers, their memory pool and the engine's per-stream scratch are all
+        private to the HIP stream the caller runs on, so several videos in flight on separate streams
+        (``PipelineConfig.concurrent_samples``) never share replay state.  Conditioning changes invalidate them."""
         self._use_graphs = enabled
         if not enabled:
             self._graphs.clear()
+            self._graph_lanes.clear()
 
     def enable_memory_optimizations(self) -> None:
         """Kept for API compatibility (ref ``svd_unet.py:166-194``); nothing to toggle here."""
@@ -193,6 +197,7 @@ class StableVideoUNet(nn.Module):
         self._image_embeddings = image_embeddings.to(dev, self.dtype).contiguous()
         self._image_latents = image_latents.to(dev, self.dtype).contiguous()
         self._conditioning_set = True
+        self._num_frames = int(num_frames)
         self._graphs.clear()          # captured graphs hold pointers to the previous conditioning tensors
         self._guidance_scale = guidance_scale
         if guidance_scale is not None and guidance_scale > 1.0:
@@ -234,6 +239,8 @@ class StableVideoUNet(nn.Module):
         self._uncond_embeddings = None
         self._uncond_image_latents = None
         self._guidance_scale_tensor = None
+        self._guidance32 = None
+        self._graphs.clear()
 
     # ------------------------------------------------------------------ one diffusion step
     def _unet_pass(self, latent, image_latents, embeddings, in_scale, step):
@@ -258,28 +265,54 @@ class StableVideoUNet(nn.Module):
             raise ValueError(f"Step {step} out of range [0, {len(self.timesteps)})")
         if latent.dtype != torch.float16 or not latent.is_cuda:
             raise ValueError("latent must be a float16 tensor on the HIP device")
+        self._check_shapes(latent)
         latent = latent.contiguous()
         if self._use_graphs:
             return self._forward_graph(latent, step)
         return self._forward_eager(latent, step)
 
+    def _check_shapes(self, latent: torch.Tensor) -> None:
+        """The kernels take raw pointers and the latent's (B, F, H, W): a conditioning tensor of another shape would be
+        read out of bounds (the reference fails in ``torch.cat`` / on broadcast, ``svd_unet.py:385-411``)."""
+        if latent.dim() != 5 or latent.shape[1] != 4:
+            raise ValueError(f"latent must be (B, 4, F, H, W); got {tuple(latent.shape)}")
+        if tuple(self._image_latents.shape) != tuple(latent.shape):
+            raise ValueError(f"image_latents {tuple(self._image_latents.shape)} do not match the latent "
+                             f"{tuple(latent.shape)} (set_conditioning was called for another batch / frame count / size)")
+        emb = self._image_embeddings
+        if emb.dim() != 3 or emb.shape[0] != latent.shape[0] or emb.shape[1] != 1 \
+                or emb.shape[2] != self.unet.cfg.cross_attention_dim:
+            raise ValueError(f"image_embeddings must be (B, 1, {self.unet.cfg.cross_attention_dim}) with B = "
+                             f"{latent.shape[0]}; got {tuple(emb.shape)}")
+        if self._guidance32 is not None and self._guidance32.numel() != latent.shape[2]:
+            raise ValueError(f"guidance was set for num_frames={self._guidance32.numel()}, the latent has "
+                             f"{latent.shape[2]} frames")
+
     def _forward_graph(self, latent: torch.Tensor, step: int) -> torch.Tensor:
-        key = (step, tuple(latent.shape))
+        # Everything a replay touches is keyed by the CALLING stream (one lane of PipelineStage's interleave = one
+        # stream): its own graph, static input/output, memory pool, and - because the engine keys its GroupNorm / fp8
+        # scratch by the stream it is enqueued on - its own capture stream.  Two lanes replaying at once therefore
+        # share nothing but the (read-only) weights and conditioning tensors.
+        lane = torch.cuda.current_stream(latent.device).cuda_stream
+        key = (lane, step, tuple(latent.shape))
         entry = self._graphs.get(key)
         if entry is None:
             self._forward_eager(latent, step)             # warm-up: lazy allocations, function attributes
             torch.cuda.synchronize(latent.device)
+            lane_state = self._graph_lanes.get(lane)
+            if lane_state is None:
+                lane_state = self._graph_lanes[lane] = [torch.cuda.Stream(device=latent.device), None]
             static_in = latent.clone()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, pool=self._graph_pool):
+            with torch.cuda.graph(graph, pool=lane_state[1], stream=lane_state[0]):
                 static_out = self._forward_eager(static_in, step)
-            if self._graph_pool is None:
-                self._graph_pool = graph.pool()
+            if lane_state[1] is None:
+                lane_state[1] = graph.pool()
             entry = self._graphs[key] = (graph, static_in, static_out)
         graph, static_in, static_out = entry
         static_in.copy_(latent)
         graph.replay()
-        return static_out.clone()                          # the static buffer is overwritten by the next replay
+        return static_out.clone()                          # the static buffer is overwritten by this lane's next replay
 
     def _forward_eager(self, latent: torch.Tensor, step: int) -> torch.Tensor:
         from ..hip import ops

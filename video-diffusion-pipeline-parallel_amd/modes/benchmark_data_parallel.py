@@ -2,8 +2,8 @@
 
 Counterpart of ``/root/reference/src/modes/benchmark_data_parallel.py`` (same flags, same ``BENCHMARK_JSON=`` keys): the
 step pipeline is the product path (north star), this harness only supplies the number the reference reports beside it
-(SURVEY.md section 8f item 4).  No communication happens during inference; timings are combined at the end with two
-collectives (max wall clock, gathered per-rank first-sample times) instead of the reference's send/recv loop.
+(SURVEY.md section 8f item 4).  No communication happens during inference; the per-rank (elapsed, count) pairs are
+combined with one all_gather instead of the reference's send/recv loop.  ``measure`` holds the measurement itself.
 """
 
 from __future__ import annotations
@@ -42,6 +42,65 @@ def parse_args(argv=None) -> argparse.Namespace:
     return p.parse_args(argv)
 
 
+def _sync(device: torch.device) -> None:
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def measure(model, *, shape, dtype, device, scale, rank: int, world: int, args) -> dict | None:
+    """The reference's measurement (``benchmark_data_parallel.py:168-247``): EVERY rank runs ``warmup_samples`` untimed
+    samples, then sync + barrier, then each rank times only its own contiguous share of the ``num_samples`` measured
+    samples.  Throughput = measured samples of all ranks / the slowest rank's measured time; first / average sample
+    time come from rank 0's measured samples.  Returns the ``BENCHMARK_JSON`` dict on rank 0, ``None`` elsewhere."""
+
+    def one_sample(seed: int) -> None:
+        torch.manual_seed(seed)
+        latent = torch.randn(shape, device=device, dtype=dtype) * scale
+        for step in range(args.total_steps):
+            latent = model(latent, step)
+
+    per_rank = -(-args.num_samples // world)                  # ceil: the last ranks may get fewer (or none)
+    first, last = rank * per_rank, min((rank + 1) * per_rank, args.num_samples)
+
+    _sync(device)
+    dist.barrier()
+    with torch.no_grad():
+        for wi in range(args.warmup_samples):
+            one_sample(args.seed + rank * 10000 + wi)
+    _sync(device)
+    dist.barrier()
+
+    times: list[float] = []
+    began = time.perf_counter()
+    with torch.no_grad():
+        for idx in range(first, last):
+            t0 = time.perf_counter()
+            one_sample(args.seed + idx)
+            _sync(device)
+            times.append(time.perf_counter() - t0)
+    mine = torch.tensor([time.perf_counter() - began, float(max(last - first, 0))], dtype=torch.float64, device=device)
+    dist.barrier()
+    everyone = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(everyone, mine)      # (the reference funnels these two numbers to rank 0 with send/recv)
+    else:
+        everyone = [mine]
+    if rank != 0:
+        return None
+    slowest = max(float(t[0]) for t in everyone)
+    measured = sum(int(t[1]) for t in everyone)
+    return {
+        "mode": "data_parallel", "world_size": world, "total_steps": args.total_steps,
+        "steps_per_gpu": args.total_steps, "model": args.model, "num_samples_measured": measured,
+        "warmup_samples": args.warmup_samples, "samples_per_rank": per_rank, "latent_shape": list(shape),
+        "first_sample_time_s": round(times[0], 4) if times else 0.0,
+        "avg_sample_time_s": round(sum(times) / len(times), 4) if times else 0.0,
+        "throughput_samples_per_s": round(measured / slowest, 4) if slowest > 0 else 0.0,
+        "wall_clock_s": round(slowest, 4),
+        "per_sample_times_ms": [round(t * 1000, 2) for t in times],
+    }
+
+
 def main(argv=None) -> None:
     args = parse_args(argv)
     logging.basicConfig(level=getattr(logging, args.log_level.upper()),
@@ -71,43 +130,8 @@ def main(argv=None) -> None:
         scale = 1.0
 
     shape = torch.Size((1, args.latent_channels, args.latent_frames, args.latent_height, args.latent_width))
-    total = args.warmup_samples + args.num_samples
-    mine = [i for i in range(total) if i % world == rank]          # disjoint sample subsets
-    measured_here = [i for i in mine if i >= args.warmup_samples]
-
-    torch.cuda.synchronize(device)
-    dist.barrier()
-    t_start = time.perf_counter()
-    ends = []
-    with torch.no_grad():
-        for i in mine:
-            torch.manual_seed(args.seed + i)
-            latent = torch.randn(shape, device=device, dtype=dtype) * scale
-            for step in range(args.total_steps):
-                latent = model(latent, step)
-            torch.cuda.synchronize(device)
-            ends.append(time.perf_counter())
-    elapsed = torch.tensor([time.perf_counter() - t_start], dtype=torch.float64, device=device)
-    first = torch.tensor([(ends[0] - t_start) if ends else 0.0], dtype=torch.float64, device=device)
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    dist.all_reduce(first, op=dist.ReduceOp.MAX)
-    counts = torch.tensor([len(measured_here)], dtype=torch.int64, device=device)
-    dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-
+    results = measure(model, shape=shape, dtype=dtype, device=device, scale=scale, rank=rank, world=world, args=args)
     if rank == 0:
-        per = [e - (t_start if k == 0 else ends[k - 1]) for k, e in enumerate(ends)]
-        wall = float(elapsed.item())
-        n_meas = int(counts.item())
-        results = {
-            "mode": "data_parallel", "world_size": world, "total_steps": args.total_steps,
-            "steps_per_gpu": args.total_steps, "model": args.model, "num_samples_measured": n_meas,
-            "warmup_samples": args.warmup_samples, "samples_per_rank": len(mine), "latent_shape": list(shape),
-            "first_sample_time_s": round(float(first.item()), 4),
-            "avg_sample_time_s": round(wall / max(len(mine), 1), 4),
-            "throughput_samples_per_s": round(total / wall, 4) if wall > 0 else 0.0,
-            "wall_clock_s": round(wall, 4),
-            "per_sample_times_ms": [round(t * 1000, 2) for t in per],
-        }
         print(f"BENCHMARK_JSON={json.dumps(results)}")
     finalize_distributed()
 
