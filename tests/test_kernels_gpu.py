@@ -255,6 +255,29 @@ def test_groupnorm(inst, rows, c, silu):
     check(y, ref)
 
 
+@pytest.mark.parametrize("inst,rows,c", [(2, 9216, 320), (1, 14 * 2304, 640), (14, 576, 1280), (14, 144, 2560),
+                                          (3, 1000, 960)])
+def test_groupnorm_large_mean_small_variance(inst, rows, c):
+    """Channels whose mean is ~50 standard deviations away from zero (real checkpoints have them): E[x^2] - mean^2 in
+    fp32 would lose the variance.  Per-group offsets (some +, some -, some none) + a per-channel offset inside groups;
+    three-launch path (shifted sums) and single-launch path (two passes over registers); vs fp64 group_norm on the
+    fp16-rounded input.  Same tolerance as the well-conditioned cases."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(c + rows + 1)
+    cpg = c // 32
+    group_off = (torch.randint(0, 3, (32,), generator=g).float() - 1.0) * 50.0          # -50, 0 or +50 sigma per group
+    chan_off = group_off.repeat_interleave(cpg) + 0.3 * torch.randn(c, generator=g)
+    x = h(torch.randn(inst, rows, c, generator=g) + chan_off)
+    gamma = torch.randn(c, generator=g); beta = torch.randn(c, generator=g)
+    ref = F.group_norm(x.double().permute(0, 2, 1), 32, gamma.double(), beta.double(), eps=1e-6)
+    ref = F.silu(ref).permute(0, 2, 1).float()
+    ws = torch.empty(ops.groupnorm_ws_bytes(inst, rows, c, 32), dtype=torch.uint8, device=DEV)
+    y = torch.empty(inst, rows, c, dtype=torch.float16, device=DEV)
+    ops.groupnorm(x.half().to(DEV), gamma.to(DEV), beta.to(DEV), y, instances=inst, rows=rows, c=c, groups=32,
+                  eps=1e-6, silu=1, ws=ws)
+    check(y, ref)
+
+
 @pytest.mark.parametrize("rows,c", [(100, 64), (1000, 320), (513, 640), (130, 1280)])
 def test_layernorm(rows, c):
     ops = _ops()

@@ -10,6 +10,11 @@
 //   cross-half exchange (wavefront-level reduction, no LDS), and the fp32 score accumulator converts
 //   in place into the B operand of O^T += V^T.P^T (the accumulator-as-operand k-order
 //   16s + 8(j>>2) + 4h + (j&3) is matched by the transposed V reads).
+//   The kernel is VALU-issue bound (32 v_exp_f32 + ~120 other VALU per 16 MFMAs), so the per-score arithmetic is cut
+//   to the exponential itself: Q is pre-multiplied by scale*log2(e) when its fragments are loaded (scores come out of
+//   the MFMA in log2 units) and the score accumulator is INITIALISED to -m (the running row maximum), so that
+//   p = exp2(acc) needs no subtract; only when a tile raises some row's maximum (rare after the first tiles) the
+//   wave subtracts the increase and rescales O and l.
 //
 // attn_temporal_kernel – sequences run across frames (14 or 25 tokens) for each pixel/head.
 //   One wave per (pixel, head); Q/K fragments are loaded straight from global memory in MFMA operand
@@ -21,6 +26,8 @@
 namespace {
 
 typedef short v4i16 __attribute__((__vector_size__(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f16x4 lds_tr16(const char *p) {
   v4i16 raw = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16 *)p);
@@ -39,8 +46,8 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
     int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int seq, int heads, float scale_log2e,
     const char *__restrict__ zero) {
   constexpr int KV = 64;
-  constexpr int K_BYTES = KV * 128, STAGE = 2 * K_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  constexpr int K_BYTES = KV * 128, STAGE = 2 * K_BYTES, RING = 2;
+  __shared__ __attribute__((aligned(16))) char smem[RING * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -50,34 +57,54 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
   const int64_t row0 = (int64_t)b * seq;
   const int q0 = blockIdx.x * 128 + wave * 32;
 
-  // Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + r][16s + 8h .. +8]
+  // Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + r][16s + 8h .. +8], pre-multiplied by scale*log2(e)
+  // (fp32 product, one rounding to fp16)
   f16x8 qf[4];
   {
     const bool ok = q0 + r < seq;
     const f16 *qp = ok ? q + (row0 + q0 + r) * ldq + hd * 64 + 8 * h : (const f16 *)zero;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const f16x8 *)(qp + (ok ? 16 * s : 0));
+    for (int s = 0; s < 4; ++s) {
+      const f16x8 raw = *(const f16x8 *)(qp + (ok ? 16 * s : 0));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[s][e] = (f16)((float)raw[e] * scale_log2e);
+    }
   }
 
-  // K/V staging: each wave moves 16 rows of K and of V per tile (2 x 2 LDS-DMA pieces of 8 rows)
+  // K/V staging: each wave moves 16 rows of K and of V per tile (2 x 2 LDS-DMA pieces of 8 rows).  Source address =
+  // wave-uniform base of the tile (advanced with scalar adds) + a per-lane byte offset that is the same for every
+  // tile; keys past `seq` (last tile only) re-read row seq-1: their scores are masked below and P = 0 meets a finite V.
   const int lrow = lane >> 3, lchunk = lane & 7;
-  const f16 *kbase = k + row0 * ldk + hd * 64;
-  const f16 *vbase = v + row0 * ldv + hd * 64;
+  const char *kb = (const char *)(k + row0 * ldk + hd * 64);
+  const char *vb = (const char *)(v + row0 * ldv + hd * 64);
+  unsigned kofl[2], vofl[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wave * 16 + i * 8 + lrow;
+    kofl[i] = (unsigned)((row * ldk + ((lchunk ^ ((row >> 1) & 7)) << 3)) * 2);
+    vofl[i] = (unsigned)((row * ldv + ((lchunk ^ (((row >> 1) & 1) << 2)) << 3)) * 2);
+  }
+  const int64_t kstep = (int64_t)KV * ldk * 2, vstep = (int64_t)KV * ldv * 2;
   auto stage = [&](int tile, int buf) {
     char *sk = smem + buf * STAGE;
     char *sv = sk + K_BYTES;
+    if ((tile + 1) * KV <= seq) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = wave * 16 + i * 8 + lrow;
-      const int key = tile * KV + row;
-      const bool ok = key < seq;
-      const f16 *ks = ok ? kbase + (int64_t)key * ldk + ((lchunk ^ ((row >> 1) & 7)) << 3)
-                         : (const f16 *)(zero + lchunk * 16);
-      const f16 *vs = ok ? vbase + (int64_t)key * ldv + ((lchunk ^ (((row >> 1) & 1) << 2)) << 3)
-                         : (const f16 *)(zero + lchunk * 16);
-      glds16(ks, sk + (wave * 16 + i * 8) * 128);
-      glds16(vs, sv + (wave * 16 + i * 8) * 128);
+      for (int i = 0; i < 2; ++i) {
+        glds16(kb + kofl[i], sk + (wave * 16 + i * 8) * 128);
+        glds16(vb + vofl[i], sv + (wave * 16 + i * 8) * 128);
+      }
+    } else {                                        // ragged last tile
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wave * 16 + i * 8 + lrow;
+        const int64_t back = max(tile * KV + row - (seq - 1), 0);     // rows to step back to stay inside the sequence
+        glds16(kb + kofl[i] - back * ldk * 2, sk + (wave * 16 + i * 8) * 128);
+        glds16(vb + vofl[i] - back * ldv * 2, sv + (wave * 16 + i * 8) * 128);
+      }
     }
+    kb += kstep;
+    vb += vstep;
   };
 
   // operand read offsets
@@ -98,12 +125,18 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
   f32x16 oacc[2];
 #pragma unroll
   for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
-  float m_run = NEG_BIG, l_run = 0.f;
+  float m_run = 0.f, l_run = 0.f;            // m_run: running row maximum in log2 units (set by the first tile)
+  f32x16 negm;                               // -m_run in all 16 accumulator positions: the C operand of the first score MFMA
+#pragma unroll
+  for (int e = 0; e < 16; ++e) negm[e] = 0.f;
 
   const int ntiles = (seq + KV - 1) / KV;
+  // 2-deep K/V ring: tile t+1 is issued while tile t is consumed and must have landed at the end of tile t.  The
+  // transposed V reads are inline asm: for the builtin hipcc puts an s_waitcnt vmcnt(0) in front of the first one
+  // (LDS-DMA in flight), which waits for the NEXT tile in the middle of this one.
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  __builtin_amdgcn_s_barrier();
   int buf = 0;
   for (int t = 0; t < ntiles; ++t) {
     if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
@@ -111,16 +144,14 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
     const char *sv = sk + K_BYTES;
     const char *sv0 = sv + vlane0, *sv1 = sv + vlane1;
 
-    // ---- S^T = K.Q^T : two 32-key sub-tiles
+    // ---- S^T = K.Q^T - m : two 32-key sub-tiles, accumulators start at minus the running maximum
     f32x16 sacc[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sacc[kt][e] = 0.f;
-#pragma unroll
       for (int s = 0; s < 4; ++s) {
         const f16x8 kf = *(const f16x8 *)(sk + koff[kt] + (((2 * s + h) ^ kswz) << 4));
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], s == 0 ? negm : sacc[kt], 0, 0, 0);
       }
     }
     // mask keys beyond seq (only the last tile can be partial)
@@ -134,55 +165,70 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
         }
     }
     // ---- online softmax for query column r (keys split over the two lane halves)
-    float mt = sacc[0][0];
+    float mt = fmaxf(fmaxf(sacc[0][0], sacc[0][1]), sacc[0][2]);
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) mt = fmaxf(mt, sacc[kt][e]);
+    for (int e = 3; e < 31; e += 2) mt = fmaxf(fmaxf(mt, sacc[e >> 4][e & 15]), sacc[(e + 1) >> 4][(e + 1) & 15]);
+    mt = fmaxf(mt, sacc[1][15]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-      const float alpha = fast_exp2((m_run - m_new) * scale_log2e);
+    // mt = (tile maximum) - m_run.  The first tile defines the reference; later tiles raise it only when a score
+    // exceeds it by more than RESCALE_LOG2 (p = 2^(s - m) <= 2^8 is exact in fp16 relative precision and l, O are fp32):
+    // with 32 query columns per wave SOME column would otherwise move in most tiles and make the whole wave rescale.
+    constexpr float RESCALE_LOG2 = 8.0f;
+    const float delta = t == 0 ? mt : (mt > RESCALE_LOG2 ? mt : 0.f);
+    if (__builtin_amdgcn_ballot_w64(delta != 0.f) != 0) {
+      const float alpha = t == 0 ? 1.f : fast_exp2(-delta);   // (first tile: l and O are still zero; -delta may be huge)
       l_run *= alpha;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
-      m_run = m_new;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[kt][e] -= delta;
+      m_run += delta;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) negm[e] = -m_run;
     }
-    const float mb = m_run * scale_log2e;
     // P -> fp16 pairwise (v_cvt_pk_f16_f32, round-to-nearest: one instruction per pair instead of two converts
     // and a pack)
-    f16x8 pf[2][2];
+    u32x4 pw[2][2];                                   // pw[kt][s] = the 8 fp16 P values of k-step s, as four packed pairs
     float lsum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
-        const float p0 = fast_exp2(sacc[kt][e] * scale_log2e - mb);
-        const float p1 = fast_exp2(sacc[kt][e + 1] * scale_log2e - mb);
+        const float p0 = fast_exp2(sacc[kt][e]);
+        const float p1 = fast_exp2(sacc[kt][e + 1]);
         lsum += p0 + p1;
-        const f16x2 pk = __builtin_convertvector((f32x2){p0, p1}, f16x2);
-        pf[kt][e >> 3][e & 7] = pk[0];
-        pf[kt][e >> 3][(e & 7) + 1] = pk[1];
+        pw[kt][e >> 3][(e & 7) >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){p0, p1}, f16x2));
       }
     l_run += lsum;
 
-    // ---- O^T += V^T . P^T
+    // ---- O^T += V^T . P^T : the 8 transposed reads of one d-tile go out together (inline asm, own lgkmcnt wait)
+    {
+      const unsigned va[2] = {(unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)sv0,
+                              (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)sv1};
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt) {
+        u32x2 vr[8];
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+        for (int i = 0; i < 8; ++i)        // i = 4*kt + 2*s + e2: keys kt*32 + 16*s + 8*e2 ..
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[i]) : "v"(va[dt]), "n"(i * 8 * 128) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[0]), "+v"(vr[1]), "+v"(vr[2]), "+v"(vr[3]), "+v"(vr[4]), "+v"(vr[5]),
+                     "+v"(vr[6]), "+v"(vr[7])::"memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          f16x8 vf;
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-          for (int e2 = 0; e2 < 2; ++e2) {
-            const f16x4 x = lds_tr16((dt ? sv1 : sv0) + (kt * 32 + 16 * s + 8 * e2) * 128);
-            vf[4 * e2 + 0] = x[0]; vf[4 * e2 + 1] = x[1]; vf[4 * e2 + 2] = x[2]; vf[4 * e2 + 3] = x[3];
+          for (int s = 0; s < 2; ++s) {
+            const u32x4 vw = {vr[4 * kt + 2 * s][0], vr[4 * kt + 2 * s][1], vr[4 * kt + 2 * s + 1][0], vr[4 * kt + 2 * s + 1][1]};
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vw), __builtin_bit_cast(f16x8, pw[kt][s]),
+                                                             oacc[dt], 0, 0, 0);
           }
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kt][s], oacc[dt], 0, 0, 0);
-        }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+      }
+    }
+    // tile t+1 landed (this wave's pieces), every wave done reading tile t's slot before it is refilled next iteration
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     buf ^= 1;
   }
 

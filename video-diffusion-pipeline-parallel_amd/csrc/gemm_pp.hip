@@ -306,7 +306,8 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       int64_t row = -1;
-      if (a_in[i]) {
+      // (EXP & 8, timing only: taps > 0 read the zero page = what an LDS-resident halo tile would save the memory pipe)
+      if (a_in[i] && !((EXP & 8) && tap > 0)) {
         if (p.mode == SP_A_CONV3X3) {
           const int ky = tap / 3, kx = tap - ky * 3;
           const int iy = a_i1[i] + ky, ix = a_i2[i] + kx;
@@ -548,6 +549,11 @@ int launch_pp(GemmArgs &a, int bm, int bn, hipStream_t s) {
   }
   if (bm == 256 && bn == 320 && a.dbg == 4) return launch_pp<256, 320, 4>(a, s);
   if (bm == 192 && bn == 256 && a.dbg == 4) return launch_pp<192, 256, 4>(a, s);
+  if (a.dbg == 8) {
+    if (bm == 256 && bn == 256) return launch_pp<256, 256, 8>(a, s);
+    if (bm == 256 && bn == 320) return launch_pp<256, 320, 8>(a, s);
+    if (bm == 192 && bn == 256) return launch_pp<192, 256, 8>(a, s);
+  }
 #endif
   if (bn == 256) {
     if (bm == 128) return launch_pp<128, 256>(a, s);

@@ -2,9 +2,10 @@
 //
 // GroupNorm: three launches.
 //   stats : grid (instances, splits); every thread owns one 8-channel octet (16-byte loads, rows
-//           strided by P), accumulates per-channel sum / sum-of-squares in fp32 registers, the block
+//           strided by P), accumulates per-channel sum / sum-of-squares of (x - ref) in fp32 registers, the block
 //           reduces them in LDS in a FIXED order (deterministic, no atomics) to per-group partials
-//           and writes [instance][split][group][2].
+//           and writes [instance][split][group][2].  ref = the group's first element of the instance's first row:
+//           sums of shifted values do not cancel when |mean| >> std (var = E[d^2] - E[d]^2 with E[d] ~ std).
 //   final : one block per instance folds the partials (fixed order, fp64) into mean / rstd.
 //   apply : streams rows: y = x*scale[c] + shift[c], optional SiLU, 16-byte loads/stores.
 // The second read of x is served mostly by the 256 MiB Infinity Cache (tensors are <= 83 MB).
@@ -26,9 +27,13 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
   const int64_t per = (rows + splits - 1) / splits;
   const int64_t r0 = (int64_t)split * per;
   int64_t r1 = r0 + per; if (r1 > rows) r1 = rows;
-  float s[8], ss[8];
+  float s[8], ss[8], ref[8];
+  const int cpg = c / groups;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+  for (int e = 0; e < 8; ++e) {
+    s[e] = ss[e] = 0.f;
+    ref[e] = o < oc ? (float)x[((int64_t)inst * rows) * c + ((o * 8 + e) / cpg) * cpg] : 0.f;
+  }
   const f16 *base = x + ((int64_t)inst * rows) * c + o * 8;
   if (pr < P) {
     // four independent 16-byte loads in flight per thread (memory-level parallelism), then accumulate
@@ -40,12 +45,12 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e]; s[e] += f; ss[e] += f * f; }
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e] - ref[e]; s[e] += f; ss[e] += f * f; }
     }
     for (; r < r1; r += P) {
       const f16x8 v = *(const f16x8 *)(base + r * c);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; ss[e] += f * f; }
+      for (int e = 0; e < 8; ++e) { const float f = (float)v[e] - ref[e]; s[e] += f; ss[e] += f * f; }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -55,7 +60,6 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
   }
   __syncthreads();
   if (tid < groups) {
-    const int cpg = c / groups;
     float a = 0.f, b = 0.f;
     for (int q = 0; q < P; ++q)
       for (int ch = tid * cpg; ch < (tid + 1) * cpg; ++ch) {
@@ -68,7 +72,7 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
 }
 
 // one block per instance: fold the per-split partials into mean / rstd (fixed order, fp64)
-__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float *__restrict__ part,
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const f16 *__restrict__ x, const float *__restrict__ part,
                                                            float *__restrict__ stats, int64_t rows, int c,
                                                            int groups, int splits, float eps) {
   __shared__ double sh[1024 * 2];
@@ -93,10 +97,12 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const float *__restri
   if (tid < groups) {
     a = 0.0; b = 0.0;
     for (int q = 0; q < slices; ++q) { a += sh[(q * groups + tid) * 2]; b += sh[(q * groups + tid) * 2 + 1]; }
-    const double cnt = (double)rows * (c / groups);
-    const double mean = a / cnt;
-    double var = b / cnt - mean * mean; if (var < 0.0) var = 0.0;
-    stats[((int64_t)inst * groups + tid) * 2] = (float)mean;
+    const int cpg = c / groups;
+    const double cnt = (double)rows * cpg;
+    const double dmean = a / cnt;                        // mean of (x - ref): of the order of the standard deviation
+    double var = b / cnt - dmean * dmean; if (var < 0.0) var = 0.0;
+    const double ref = (double)(float)x[((int64_t)inst * rows) * c + tid * cpg];
+    stats[((int64_t)inst * groups + tid) * 2] = (float)(ref + dmean);
     stats[((int64_t)inst * groups + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
@@ -178,38 +184,55 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(const f16 *__restrict__ x
   const bool act = rr < rp;
   const int nrows = (int)rows;
   hv v[MAXIT];
+  bool live[MAXIT];
   float s = 0.f, ss = 0.f;
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const int r = rr + it * rp;
-    if (act && r < nrows) {
+    live[it] = act && r < nrows;
+    if (live[it]) {
       v[it] = *(const hv *)(xb + (int64_t)r * c + q * VEC);
     } else {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) v[it][e] = (f16)0.f;
     }
   }
+  // two passes over the registers: the mean first, then the sum of squared deviations (no E[x^2] - mean^2 cancellation)
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it)
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { const float f = (float)v[it][e]; s += f; ss += f * f; }
-  // keep the slab PACKED across the reduction (otherwise the compiler keeps the fp32 copies alive: 2x the registers)
+    for (int e = 0; e < VEC; ++e) s += (float)v[it][e];
+  // keep the slab PACKED across the reductions (otherwise the compiler keeps the fp32 copies alive: 2x the registers)
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) asm volatile("" : "+v"(v[it]));
-  s = wave_sum(s); ss = wave_sum(ss);
-  if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = ss; }
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
   __syncthreads();
   if (tid == 0) {
-    double a = 0.0, b = 0.0;
-    for (int w = 0; w < 8; ++w) { a += red[w * 2]; b += red[w * 2 + 1]; }
-    const double cnt = (double)rows * cpg;
-    const double mean = a / cnt;
-    double var = b / cnt - mean * mean; if (var < 0.0) var = 0.0;
-    red[16] = (float)mean;
-    red[17] = (float)(1.0 / sqrt(var + (double)eps));
+    double a = 0.0;
+    for (int w = 0; w < 8; ++w) a += red[w];
+    red[16] = (float)(a / ((double)rows * cpg));
   }
   __syncthreads();
-  const float mean = red[16], rstd = red[17];
+  const float mean = red[16];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+    if (live[it]) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { const float d = (float)v[it][e] - mean; ss += d * d; }
+    }
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) asm volatile("" : "+v"(v[it]));
+  ss = wave_sum(ss);
+  if (lane == 0) red[8 + wave] = ss;
+  __syncthreads();
+  if (tid == 0) {
+    double b = 0.0;
+    for (int w = 0; w < 8; ++w) b += red[8 + w];
+    red[17] = (float)(1.0 / sqrt(b / ((double)rows * cpg) + (double)eps));
+  }
+  __syncthreads();
+  const float rstd = red[17];
   float sc[VEC], sf[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
@@ -221,7 +244,7 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(const f16 *__restrict__ x
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const int r = rr + it * rp;
-    if (act && r < nrows) {
+    if (live[it]) {
       hv w;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
@@ -350,8 +373,8 @@ extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *
   blocks_y = (rows + rpb - 1) / rpb;
   SP_CLEAR_STALE_ERROR();
   float *stats = (float *)ws + (size_t)instances * splits * groups * 2;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(instances), dim3(1024), 0, s, (const float *)ws, stats, rows, c,
-                     groups, splits, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(instances), dim3(1024), 0, s, (const f16 *)x, (const float *)ws, stats,
+                     rows, c, groups, splits, eps);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(instances, (unsigned)blocks_y), dim3(threads), 0, s,
                      (const f16 *)x, (const float *)stats, gamma, beta, (f16 *)y, rows, c, groups, fuse_silu,
                      rpb);
