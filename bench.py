@@ -41,6 +41,47 @@ PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-
 FRAMES, LAT_H, LAT_W, TOTAL_STEPS = 14, 72, 128, 25
 
 
+class Watchdog:
+    """Hard wall-clock guard for multi-rank runs: a rank that makes no progress for `limit` seconds prints where it
+    was and leaves with exit status 3 (a fresh exit of this process; nothing is re-executed), so that a stuck
+    collective or hand-off yields a diagnosable log instead of a silent hang until the launcher's own limit."""
+
+    def __init__(self, limit: float, rank: int):
+        import threading
+        self.limit, self.rank = limit, rank
+        self.where, self.last = "start", time.monotonic()
+        self._stop = threading.Event()
+        if limit > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def beat(self, where: str) -> None:
+        self.where, self.last = where, time.monotonic()
+
+    def stop(self) -> None:
+        self._stop.set()
+
+    def _run(self) -> None:
+        while not self._stop.wait(1.0):
+            idle = time.monotonic() - self.last
+            if idle > self.limit:
+                print(f"[rank {self.rank}] WATCHDOG: no progress for {idle:.0f} s at '{self.where}'; exiting with status 3",
+                      file=sys.stderr, flush=True)
+                os._exit(3)
+
+
+def describe_rank(rank, n, device, ring, rotating, conc, selftest):
+    """One stderr line per rank before the timed region: what a failed scaling run needs for its post-mortem."""
+    backend = dist.get_backend() if n > 1 else "none"
+    try:
+        rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as exc:  # noqa: BLE001
+        rccl = f"unavailable ({exc!r})"
+    sched = "single GPU" if n == 1 else ("ring" if ring else "chain" + (" + rotating extra step" if rotating else ""))
+    print(f"[rank {rank}/{n}] device {device} ({torch.cuda.get_device_name(device)}), torch {torch.__version__}, "
+          f"backend {backend}, RCCL {rccl}, schedule {sched}, {conc} videos in flight, ring self-test: {selftest}, "
+          f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,9 +98,14 @@ def parse():
     ap.add_argument("--no-rotate", action="store_true",
                     help="N>1: keep the extra step of the balanced split on the first ranks for every video "
                          "(default: rotate it with the video index so no stage is a permanent bottleneck)")
-    ap.add_argument("--no-ring", action="store_true",
-                    help="N>1: chain of stages (rank 0 feeds, last rank finishes) instead of the ring schedule "
-                         "(video i starts on rank i mod N; no pipeline fill/drain inside the timed region)")
+    ap.add_argument("--ring", action="store_true",
+                    help="N>1: ring schedule (video i starts on rank i mod N and visits every rank once: no pipeline "
+                         "fill/drain inside the timed region) instead of the reference's chain of stages (rank 0 feeds, "
+                         "last rank finishes).  Experimental: its grouped RCCL exchange has only run over Gloo so far; "
+                         "a self-test runs first and every rank falls back to the chain if it fails")
+    ap.add_argument("--no-ring", action="store_true", help="(default now; kept for older command lines)")
+    ap.add_argument("--watchdog", type=float, default=120.0,
+                    help="seconds without progress after which a rank prints where it is and exits with status 3")
     ap.add_argument("--fp8-attention", action="store_true",
                     help="spatial self-attention on fp8-e4m3 MFMA (BASELINE config 5; use with --frames 25 --total-steps 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,42 +140,83 @@ def cpu_baseline(frames_full, h, w, total_steps):
     scale = unet_flops(cfg, frames_full, h, w)["total"] / unet_flops(cfg, sample_frames, h, w)["total"]
     videos_per_s = 1.0 / (dt * scale * total_steps)
     del ref
-    return {"value": videos_per_s, "unit": "videos/s", "cores": threads, "kind": "port",
+    return {"value": videos_per_s, "unit": "videos/s", "cores": threads, "host_cores": cores, "kind": "port",
             "sample": f"oracle fp32 UNet (torch CPU), 1 forward at {sample_frames} of {frames_full} frames "
                       f"{h}x{w} in {dt:.1f}s, scaled by FLOP ratio {scale:.2f} x {total_steps} steps"}
 
 
+def _sim_worker(rank, ws, init_file, out_file, c, hid, shape, steps, reps, threads):
+    import logging
+
+    from vdpp_amd.models import DummyUNet
+    from vdpp_amd.pipeline import run_single_latent
+
+    torch.set_num_threads(threads)
+    init_distributed(backend="gloo", rank=rank, world_size=ws, init_method=f"file://{init_file}")
+    torch.manual_seed(1234)                      # same weights on every rank (the reference CLI forgets this)
+    model = DummyUNet(c, hid)
+    x = torch.randn(shape)
+    spec = LatentSpec(shape=x.shape, dtype=torch.float32, device=torch.device("cpu"))
+    ts = list(reversed(range(steps)))
+    quiet = logging.getLogger("bench.quiet"); quiet.setLevel(logging.ERROR)
+    kw = dict(total_steps=steps, timesteps=ts, world_size=ws, rank=rank, latent_spec=spec,
+              input_latent=x if rank == 0 else None, logger=quiet)
+    with torch.no_grad():
+        run_single_latent(model, **kw)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run_single_latent(model, **kw)
+        dist.barrier()
+        dt = (time.perf_counter() - t0) / reps
+    if rank == 0:
+        torch.save(dt, out_file)
+    finalize_distributed()
+
+
+def _sim_time(ws, c, hid, shape, steps, reps, threads):
+    """Seconds per sample of the reference's simulator-mode path (ref src/modes/simulator.py:95-164: DummyUNet, Gloo,
+    CPU) through this repo's executor, `ws` processes with `threads` torch threads each."""
+    import tempfile
+
+    import torch.multiprocessing as mp
+
+    with tempfile.TemporaryDirectory() as td:
+        out_file = os.path.join(td, "t.pt")
+        mp.spawn(_sim_worker, args=(ws, os.path.join(td, "init"), out_file, c, hid, shape, steps, reps, threads),
+                 nprocs=ws, join=True)
+        return float(torch.load(out_file))
+
+
 def cpu_simulator():
-    """The reference's CPU simulator-mode path (DummyUNet(8,16), latent (1,8,8,32,32) fp32, 8 steps)."""
+    """The reference's CPU simulator-mode path timed on this host (BASELINE.md section 3 / SURVEY 8d): DummyUNet(8,16) on
+    (1,8,8,32,32) fp32, 8 steps, world_size 1 and 2 over Gloo; DummyUNet(4,64) on the SVD latent (1,4,14,72,128); and
+    the scalar C oracle of the same arithmetic."""
     import numpy as np
 
     from oracle import dummy_ref
     from vdpp_amd.models import DummyUNet
-    from vdpp_amd.pipeline import run_single_latent
 
+    cores = os.cpu_count() or 1
+    out = {"host_cores": cores, "rows": []}
+    for ws, c, hid, shape, steps, reps in ((1, 8, 16, (1, 8, 8, 32, 32), 8, 5), (2, 8, 16, (1, 8, 8, 32, 32), 8, 5),
+                                           (1, 4, 64, (1, 4, 14, 72, 128), 8, 2), (2, 4, 64, (1, 4, 14, 72, 128), 8, 2)):
+        threads = max(1, min(cores, 16) // ws)
+        dt = _sim_time(ws, c, hid, shape, steps, reps, threads)
+        out["rows"].append({"workload": f"DummyUNet({c},{hid}) {tuple(shape)} fp32, {steps} steps", "world_size": ws,
+                            "backend": "gloo", "threads_per_rank": threads, "samples_per_s": 1.0 / dt,
+                            "ms_per_step": 1e3 * dt / steps})
     torch.manual_seed(1234)
     model = DummyUNet(8, 16)
     x = torch.randn(1, 8, 8, 32, 32)
-    spec = LatentSpec(shape=x.shape, dtype=torch.float32, device=torch.device("cpu"))
     ts = list(reversed(range(8)))
-    import logging
-    quiet = logging.getLogger("bench.quiet"); quiet.setLevel(logging.ERROR)
-    with torch.no_grad():
-        run_single_latent(model, total_steps=8, timesteps=ts, world_size=1, rank=0, latent_spec=spec,
-                          input_latent=x, logger=quiet)
-        t0 = time.perf_counter(); reps = 5
-        for _ in range(reps):
-            run_single_latent(model, total_steps=8, timesteps=ts, world_size=1, rank=0, latent_spec=spec,
-                              input_latent=x, logger=quiet)
-        t_torch = (time.perf_counter() - t0) / reps
     params = {k: v.numpy() for k, v in model.state_dict().items()}
     dummy_ref.run_steps(x.numpy(), ts, 0, 8, params)
     t0 = time.perf_counter()
     dummy_ref.run_steps(x.numpy(), ts, 0, 8, params)
-    t_c = time.perf_counter() - t0
-    return {"workload": "DummyUNet(8,16) (1,8,8,32,32) fp32, 8 steps, world_size 1",
-            "torch_cpu_samples_per_s": 1.0 / t_torch, "torch_threads": torch.get_num_threads(),
-            "c_oracle_samples_per_s": 1.0 / t_c, "c_oracle_threads": 1}
+    out["c_oracle"] = {"workload": "DummyUNet(8,16) (1,8,8,32,32) fp32, 8 steps (oracle/dummy_unet_ref.c, scalar)",
+                       "threads": 1, "samples_per_s": 1.0 / (time.perf_counter() - t0)}
+    return out
 
 
 def main():
@@ -150,10 +237,14 @@ def main():
         local_rank %= max(1, torch.cuda.device_count())
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
+    dog = Watchdog(args.watchdog if n > 1 else 0.0, rank)
     if n > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dog.beat("init_process_group")
         init_distributed(backend=resolve_backend(None, simulator=False), rank=rank, world_size=n)
+        dog.beat("first barrier")
         dist.barrier()      # create the world communicator collectively, before the first grouped send/recv needs it
+        dog.beat("model construction")
 
     from vdpp_amd.models.unet_spec import UNetConfig, forward_flops
     from vdpp_amd.hip import ops
@@ -170,8 +261,10 @@ def main():
     spec = LatentSpec(shape=shape, dtype=torch.float16, device=device)
     import logging
     quiet = logging.getLogger("bench.quiet"); quiet.setLevel(logging.ERROR)
-    ring = n > 1 and not args.no_ring
+    ring = n > 1 and args.ring and not args.no_ring
+    selftest = "not requested"
     if ring:
+        dog.beat("ring self-test")
         # self-test of the grouped neighbour exchange the ring schedule relies on (also warms the communicator);
         # if any rank cannot do it, every rank falls back to the chain schedule
         ok = torch.ones(1, device=device)
@@ -190,11 +283,22 @@ def main():
             ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         ring = bool(ok.item() > 0)
+        selftest = "passed" if ring else "FAILED on some rank (chain schedule used)"
     rotating = n > 1 and not ring and not args.no_rotate
     stage = PipelineStage(model, PipelineConfig(total_steps=T, world_size=n, rank=rank, timesteps=list(range(T)),
                                                 latent_spec=spec, balanced=True, concurrent_samples=conc,
                                                 rotate=rotating, ring=ring),
                           logger=quiet)
+    describe_rank(rank, n, device, ring, rotating, conc, selftest)
+    steps_done = [0]
+    inner_model = model.forward
+
+    if n > 1:           # heartbeat: every UNet step enqueued on this rank counts as progress
+        def beating_forward(latent, step):
+            steps_done[0] += 1
+            dog.beat(f"UNet step {step} (#{steps_done[0]} on this rank)")
+            return inner_model(latent, step)
+        model.forward = beating_forward
     gen = torch.Generator(device=device)
 
     def supplier(i):
@@ -209,8 +313,10 @@ def main():
 
     with torch.no_grad():
         if warmup > 0:
+            dog.beat("warm-up")
             stage.run_many(warmup, input_supplier=supplier if (rank == 0 or ring) else None)
             stage.drain()
+        dog.beat("fence before the timed region")
         fence()
         done_events = []
 
@@ -222,8 +328,10 @@ def main():
         start_ev = torch.cuda.Event(enable_timing=True); start_ev.record()
         stage.run_many(steps, input_supplier=(lambda i: supplier(warmup + i)) if (rank == 0 or ring) else None)
         stage.drain()
+        dog.beat("fence after the timed region")
         fence()
         elapsed = time.perf_counter() - t0
+    dog.beat("reduction of the timings")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if n > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -297,21 +405,30 @@ def main():
             torch.cuda.synchronize(device)
             prof, ops.PROFILE = ops.PROFILE, None
         by = {}
-        for kind, fl, e0, e1 in prof:
-            acc = by.setdefault(kind, [0.0, 0.0, 0])
-            acc[0] += fl; acc[1] += e0.elapsed_time(e1) / 1e3; acc[2] += 1
-        gf, gt, gn = by["gemm"]
-        traffic, traffic_src = None, None
-        try:  # PMC-derived bytes per launch are collected off-line (tools/pmc_forward.sh) and committed
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = (pj["fabric_read_bytes"] + pj["write_bytes"]) / pj["launches"]
-            traffic_src = pj["source"]
-        except Exception:
-            pass
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_f16_kernel (implicit-GEMM conv/linear)",
+        for kind, fl, e0, e1, nb in prof:
+            acc = by.setdefault(kind, [0.0, 0.0, 0, 0.0])
+            acc[0] += fl; acc[1] += e0.elapsed_time(e1) / 1e3; acc[2] += 1; acc[3] += nb
+        gf, gt, gn, gb = by["gemm"]
+        # HBM/fabric bytes per launch come from PMC passes (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE) that
+        # cannot run inside this process; they are collected with tools/pmc_forward.sh on a named commit and committed.
+        # The line carries that commit and the algorithmic bytes (every operand / output / residual element once,
+        # measured from this run's launches) so that the over-fetch ratio can be read off directly.
+        traffic, traffic_src, traffic_commit = None, None, None
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                traffic = (pj["fabric_read_bytes"] + pj["write_bytes"]) / pj["launches"]
+                traffic_src, traffic_commit = pj["source"], pj.get("commit", "f08fa7c (round 1 final build)")
+                break
+            except Exception:
+                continue
+        out["roofline"] = {"bound": "mfma",
+                           "kernel": "gemm_pp_kernel / gemm_ps_kernel / gemm_f16_kernel (implicit-GEMM conv/linear)",
                            "achieved": gf / gt / 1e12, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                            "frac": gf / gt / 1e12 / PEAK_FP16_TFLOPS, "traffic": traffic,
-                           "traffic_source": traffic_src,
+                           "traffic_source": traffic_src, "traffic_measured_at_commit": traffic_commit,
+                           "algorithmic_bytes_per_launch": gb / gn,
+                           "traffic_over_algorithmic": (traffic / (gb / gn)) if traffic else None,
                            "launches_per_forward": gn, "avg_launch_us": 1e6 * gt / gn,
                            "flop_per_launch_avg": gf / gn}
         if "attn_spatial" in by:
@@ -328,8 +445,10 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if n > 1:
+        dog.beat("final barrier (rank 0 measures the per-kernel roofline alone before it)")
         dist.barrier()          # rank 0 ran the roofline leg alone; leave together
         finalize_distributed()
+    dog.stop()
 
 
 if __name__ == "__main__":

@@ -3,6 +3,7 @@
 import argparse
 import os
 import tempfile
+import time
 
 import torch
 import torch.multiprocessing as mp
@@ -21,6 +22,7 @@ def _dp_worker(rank, ws, init_file, out_file, num_samples, warmup):
 
     def spy(latent, step):
         calls.append(step)
+        time.sleep(0.004)               # samples of >= 12 ms: the report rounds times to 0.1 ms
         return model(latent, step)
 
     args = argparse.Namespace(total_steps=3, num_samples=num_samples, warmup_samples=warmup, seed=7, model="dummy")
@@ -49,6 +51,6 @@ def test_data_parallel_measurement_follows_the_reference():
         assert res["num_samples_measured"] == n and res["warmup_samples"] == warm
         assert res["samples_per_rank"] == per_rank and res["world_size"] == ws
         assert len(res["per_sample_times_ms"]) == min(per_rank, n)          # rank 0's measured samples only
-        assert abs(res["throughput_samples_per_s"] - n / res["wall_clock_s"]) < 1e-2 * res["throughput_samples_per_s"] + 1e-3
+        assert abs(res["throughput_samples_per_s"] - n / res["wall_clock_s"]) < 2e-2 * res["throughput_samples_per_s"]
         assert res["first_sample_time_s"] > 0 and res["avg_sample_time_s"] > 0
         assert res["mode"] == "data_parallel" and res["steps_per_gpu"] == res["total_steps"] == 3

@@ -32,7 +32,7 @@ def main():
     print("forward ms (with event overhead):", t0.elapsed_time(t1))
     gi = 0
     agg = collections.OrderedDict()
-    for kind, fl, e0, e1 in prof:
+    for kind, fl, e0, e1, _nb in prof:
         ms = e0.elapsed_time(e1)
         if kind == "gemm":
             key = ("gemm",) + shapes[gi]; gi += 1

@@ -182,6 +182,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
   }
 }
 
+#ifdef SP_GEMM_EXPERIMENTS
 // COMPUTE phase of one K-step with this wave's LDS-DMA pieces for K-step kt+3 spread between its MFMAs (an LDS-DMA
 // piece costs the issuing wave ~60 cycles among MFMAs but 100-185 in a phase that also carries ds_reads).  One
 // MFMA stream for every wave; `pieces` is a wave-uniform bit mask (bit pc: issue piece pc; A pieces first).
@@ -211,6 +212,7 @@ __device__ __forceinline__ void mfma_block(f32x4 (&acc)[TN][TM], const f16x8 (&f
     }
   }
 }
+#endif
 
 // BM = 256: one workgroup of 8 waves per CU (4-deep ring).  BM = 192: same, for row counts where 256-row tiles leave a
 // third of the CUs idle in the only round (8064 rows x 1280 columns).  BM = 128: FOUR waves (1 x 4, the same 128 x BN/4
@@ -306,8 +308,12 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       int64_t row = -1;
+#ifdef SP_GEMM_EXPERIMENTS
       // (EXP & 8, timing only: taps > 0 read the zero page = what an LDS-resident halo tile would save the memory pipe)
       if (a_in[i] && !((EXP & 8) && tap > 0)) {
+#else
+      if (a_in[i]) {
+#endif
         if (p.mode == SP_A_CONV3X3) {
           const int ky = tap / 3, kx = tap - ky * 3;
           const int iy = a_i1[i] + ky, ix = a_i2[i] + kx;
@@ -427,8 +433,10 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
   PP_TRACE(1);
   PP_TRACE_CLK(8);
 
-  constexpr int dbg = EXP;   // timing experiments only (0 in production): 1 no DMA in loop, 2 no MFMA, 64 no ds_read
-  constexpr bool DMA_IN_COMPUTE = (dbg & 4) != 0;   // experiment: LDS-DMA pieces interleaved with the MFMAs
+#ifdef SP_GEMM_EXPERIMENTS
+  constexpr int dbg = EXP;   // timing experiments only: 1 no DMA in loop, 2 no MFMA, 4 DMA between MFMAs, 64 no ds_read
+  constexpr bool DMA_IN_COMPUTE = (dbg & 4) != 0;
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     // ---- READ phase: operand fragments first, then the LDS-DMA for K-step kt+3.  The DMA instructions
     // queue behind the CU's single 64 B/clk texture-address path (about 100 cycles each when four waves issue
@@ -438,26 +446,35 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
     read_slot = read_slot + 1 == PSTAGES ? 0 : read_slot + 1;
     const char *sb = sa + A_BYTES;
     f16x8 fw[TN], fa[TM];
-    if (!(dbg & 64) || kt == 0) {  // (dbg is constexpr)
-#pragma unroll
-      for (int i = 0; i < TN; ++i) fw[i] = *(const f16x8 *)(sb + offw[i]);
-#pragma unroll
-      for (int j = 0; j < TM; ++j) fa[j] = *(const f16x8 *)(sa + offa[j]);
-    } else {
+#ifdef SP_GEMM_EXPERIMENTS
+    if ((dbg & 64) && kt > 0) {
 #pragma unroll
       for (int i = 0; i < TN; ++i) fw[i] = (f16x8){1, 2, 3, 4, 5, 6, 7, (f16)kt};
 #pragma unroll
       for (int j = 0; j < TM; ++j) fa[j] = (f16x8){1, 2, 3, 4, 5, 6, 7, (f16)lane};
+    } else
+#endif
+    {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fw[i] = *(const f16x8 *)(sb + offw[i]);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) fa[j] = *(const f16x8 *)(sa + offa[j]);
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef SP_GEMM_EXPERIMENTS
     if constexpr (DMA_IN_COMPUTE) {
       if (issue && in_tap == cpt) { ++tap; in_tap = 0; set_tap(tap); }     // addresses for the coming pieces
       // late waves: this wave's pieces of K-step kt+1 must have landed; kt+2 may stay in flight (kt+3 not issued yet)
       int left = min(PDIST - 2, nk - 2 - kt);
       if (left < 0) left = 0;
       if (late) wait_dma<L_LATE>(left);
-    } else {
-      if constexpr (!(dbg & 1)) { if (issue) stage_next(); }
+    } else
+#endif
+    {
+#ifdef SP_GEMM_EXPERIMENTS
+      if constexpr (!(dbg & 1))
+#endif
+      { if (issue) stage_next(); }
       // K-steps issued beyond kt+1 so far: up to kt+PDIST
       int left = min(PDIST - 1, nk - 2 - kt);
       if (left < 0) left = 0;
@@ -469,6 +486,7 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
     __builtin_amdgcn_sched_barrier(0);
     // ---- COMPUTE phase
     __builtin_amdgcn_s_setprio(1);
+#ifdef SP_GEMM_EXPERIMENTS
     if constexpr (DMA_IN_COMPUTE) {
       char *dsa = smem + stage_slot * STAGE + wave * 1024;
       char *dsb = dsa + A_BYTES;
@@ -486,18 +504,20 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
         stage_slot = stage_slot + 1 == PSTAGES ? 0 : stage_slot + 1;
         ++staged; ++in_tap;
       }
-    } else if constexpr (!(dbg & 2)) {
+    } else if constexpr ((dbg & 2) != 0) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(fw[i]));
+#pragma unroll
+      for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(fa[j]));
+    } else
+#endif
+    {
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
 #pragma unroll
         for (int j = 0; j < TM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(fw[i]));
-#pragma unroll
-      for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(fa[j]));
     }
     __builtin_amdgcn_s_setprio(0);
     if (!late) wait_dma<L_EARLY>(min(PDIST - 1, max(nk - 2 - kt, 0)));

@@ -20,13 +20,13 @@ class HipKernelError(RuntimeError):
 
 # Optional per-launch timing (bench.py roofline leg): when a list is installed here, the contraction
 # and attention wrappers bracket their launch with events on the launching stream and append
-# (kind, flops, start_event, end_event).
+# (kind, flops, start_event, end_event, algorithmic_bytes).
 PROFILE = None
 
 
 class _Timed:
-    def __init__(self, kind, flops):
-        self.kind, self.flops = kind, flops
+    def __init__(self, kind, flops, nbytes=0.0):
+        self.kind, self.flops, self.nbytes = kind, flops, nbytes
 
     def __enter__(self):
         if PROFILE is not None:
@@ -38,7 +38,7 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.nbytes))
         return False
 
 
@@ -100,7 +100,10 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
     d.d = _rows(out, "out", d.ldd).data_ptr()
     d.zero_page = zero_page(a.device).data_ptr()
     taps = 9 if mode == A_CONV3X3 else 3 if mode == A_TEMPORAL3 else 1
-    with _Timed("gemm", 2.0 * m * n * taps * cin):
+    # algorithmic bytes of this launch: every operand element once (A without tap re-reads), output and residuals once
+    a_rows = d.n_img * d.hin * d.win if mode == A_CONV3X3 else m
+    nbytes = 2.0 * (a_rows * cin + n * taps * cin + m * (n_store or nout) * (1 + (res1 is not None) + (res2 is not None)))
+    with _Timed("gemm", 2.0 * m * n * taps * cin, nbytes):
         _check(load().sp_gemm_f16(ctypes.byref(d), _stream()), "sp_gemm_f16")
     return out
 
