@@ -54,3 +54,17 @@ def test_data_parallel_measurement_follows_the_reference():
         assert abs(res["throughput_samples_per_s"] - n / res["wall_clock_s"]) < 2e-2 * res["throughput_samples_per_s"]
         assert res["first_sample_time_s"] > 0 and res["avg_sample_time_s"] > 0
         assert res["mode"] == "data_parallel" and res["steps_per_gpu"] == res["total_steps"] == 3
+
+
+def test_comparison_csv_schema_is_the_references():
+    """ref scripts/benchmark_comparison.sh:47-71: header and one row per BENCHMARK_JSON line."""
+    from vdpp_amd.modes import comparison
+
+    assert ",".join(comparison.CSV_HEADER) == \
+        "mode,gpu_count,total_steps,steps_per_gpu,num_samples,first_sample_s,avg_sample_s,throughput_sps"
+    log = "noise\nBENCHMARK_JSON={\"steps_per_gpu\": 99}\nmore\nBENCHMARK_JSON=" + \
+          '{"steps_per_gpu": 4, "first_sample_time_s": 8.7, "avg_sample_time_s": 8.5, "throughput_samples_per_s": 0.1178}\n'
+    res = comparison.extract_json(log)                      # the LAST line wins (tail -1 in the reference)
+    assert res["steps_per_gpu"] == 4
+    assert comparison.csv_row("pipeline_parallel", 7, 28, 14, res) == ["pipeline_parallel", 7, 28, 4, 14, 8.7, 8.5, 0.1178]
+    assert comparison.extract_json("nothing here") is None

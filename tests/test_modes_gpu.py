@@ -1,0 +1,66 @@
+"""Single-rank smoke tests of the mode entry points on the GPU (counterparts of the reference's
+``python -m src.modes.{benchmark,benchmark_data_parallel,production}``): they run end to end in this process, print the
+reference's ``BENCHMARK_JSON=`` line (ref src/modes/benchmark.py:269-313, benchmark_data_parallel.py:232-274) and the
+numbers in it are consistent."""
+
+import json
+import logging
+import re
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(monkeypatch, tmp_path):
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "1"); monkeypatch.setenv("LOCAL_RANK", "0")
+    return ["--backend", "gloo", "--init-method", f"file://{tmp_path}/rendezvous", "--log-level", "WARNING"]
+
+
+def _json_line(capsys):
+    out = capsys.readouterr().out
+    m = re.search(r"^BENCHMARK_JSON=(\{.*\})$", out, flags=re.M)
+    assert m, out[-2000:]
+    return json.loads(m.group(1))
+
+
+@pytest.mark.parametrize("model", ["dummy", "svd"])
+def test_benchmark_mode_prints_the_reference_json(monkeypatch, tmp_path, capsys, model):
+    from vdpp_amd.modes import benchmark
+    argv = _env(monkeypatch, tmp_path) + ["--model", model, "--total-steps", "4", "--num-samples", "3", "--warmup-samples", "1"]
+    size = ["2", "8", "8"] if model == "svd" else ["4", "16", "16"]
+    argv += ["--latent-frames", size[0], "--latent-height", size[1], "--latent-width", size[2]]
+    benchmark.main(argv)
+    r = _json_line(capsys)
+    assert r["world_size"] == 1 and r["total_steps"] == 4 and r["steps_per_gpu"] == 4 and r["model"] == model
+    assert r["num_samples_measured"] == 3 and r["warmup_samples"] == 1 and r["fsdp"] is False
+    assert len(r["per_sample_times_ms"]) == 4                      # warm-up + measured completions on the last rank
+    measured = r["per_sample_times_ms"][1:]
+    assert abs(r["avg_sample_time_s"] - sum(measured) / 3e3) < 1e-3
+    assert abs(r["throughput_samples_per_s"] - 3e3 / sum(measured)) <= 0.02 * r["throughput_samples_per_s"]
+    assert r["latent_shape"][1] == 4 and r["max_peak_memory_gb"] >= 0.0 and len(r["peak_memory_gb_per_rank"]) == 1
+    assert not torch.distributed.is_initialized()
+
+
+def test_data_parallel_mode_prints_the_reference_json(monkeypatch, tmp_path, capsys):
+    from vdpp_amd.modes import benchmark_data_parallel as dp
+    argv = _env(monkeypatch, tmp_path) + ["--model", "dummy", "--total-steps", "3", "--num-samples", "4", "--warmup-samples", "2",
+                                         "--latent-frames", "4", "--latent-height", "16", "--latent-width", "16"]
+    dp.main(argv)
+    r = _json_line(capsys)
+    assert r["mode"] == "data_parallel" and r["world_size"] == 1 and r["num_samples_measured"] == 4
+    assert r["samples_per_rank"] == 4 and len(r["per_sample_times_ms"]) == 4 and r["warmup_samples"] == 2
+    assert r["throughput_samples_per_s"] > 0 and r["wall_clock_s"] > 0 and r["steps_per_gpu"] == 3
+    assert not torch.distributed.is_initialized()
+
+
+def test_production_mode_runs_the_svd_pipeline(monkeypatch, tmp_path, caplog):
+    from vdpp_amd.modes import production
+    argv = _env(monkeypatch, tmp_path)[:-2] + ["--log-level", "INFO", "--random-init", "--total-steps", "3", "--num-samples", "2",
+                                               "--latent-frames", "2", "--latent-height", "8", "--latent-width", "8"]
+    with caplog.at_level(logging.INFO):
+        production.main(argv)
+    norms = [float(m.group(1)) for m in re.finditer(r"final latent norm: ([0-9.eE+-]+)", caplog.text)]
+    assert len(norms) == 2 and all(n > 0 and n == n and n != float("inf") for n in norms)
+    assert not torch.distributed.is_initialized()
