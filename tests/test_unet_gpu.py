@@ -273,16 +273,19 @@ def test_graph_replay_with_two_videos_in_flight():
     spec = LatentSpec(shape=shape, dtype=torch.float16, device=torch.device(DEV))
     xs = [(torch.randn(shape) * 20 * (i + 1)).half().to(DEV) for i in range(6)]
 
-    def run(model, conc):
-        stage = PipelineStage(model, PipelineConfig(total_steps=steps, world_size=1, rank=0, timesteps=list(range(steps)),
-                                                    latent_spec=spec, concurrent_samples=conc))
+    def stage_of(model, conc):
+        return PipelineStage(model, PipelineConfig(total_steps=steps, world_size=1, rank=0, timesteps=list(range(steps)),
+                                                   latent_spec=spec, concurrent_samples=conc))
+
+    def run(stage):
         out = stage.run_many(len(xs), input_supplier=lambda i: xs[i])
         torch.cuda.synchronize()
         return out
 
-    want = run(eager, 1)
+    want = run(stage_of(eager, 1))
+    two_lanes = stage_of(graphed, 2)             # one stage = one pair of lane streams
     for trial in range(2):                       # first pass captures (per lane), second pass only replays
-        got = run(graphed, 2)
+        got = run(two_lanes)
         for i, (a, b) in enumerate(zip(want, got)):
             assert torch.equal(a, b), f"trial {trial} sample {i}"
     lanes = {k[0] for k in graphed._graphs}
