@@ -432,7 +432,7 @@ def main():
                            "launches_per_forward": gn, "avg_launch_us": 1e6 * gt / gn,
                            "flop_per_launch_avg": gf / gn}
         if "attn_spatial" in by:
-            af, at, an = by["attn_spatial"]
+            af, at, an, _ = by["attn_spatial"]
             out["roofline_attention"] = {"bound": "mfma", "kernel": "attn_spatial_kernel",
                                          "achieved": af / at / 1e12, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                                          "frac": af / at / 1e12 / PEAK_FP16_TFLOPS, "launches_per_forward": an,

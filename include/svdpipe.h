@@ -78,6 +78,12 @@ typedef struct sp_gemm_desc {
   int n_store;          /* number of leading output columns actually stored (<= Nout); 0 = all */
   void *d; int64_t ldd; /* fp16 [m][ldd] */
   const void *zero_page;
+  /* LayerNorm folded into this contraction (SP_A_LINEAR only, bias2 must be NULL): with W pre-multiplied by the norm's
+     gamma, LN(x).W^T + b = rstd[m]*(x.W'^T - mean[m]*ln_colsum[n]) + bias[n], so the normalised tensor is never
+     written: ln_stats = fp32 [m][2] (mean, rstd) from sp_ln_stats_f16, ln_colsum[n] = sum_k W'[n][k] (of the fp16
+     values), bias[n] = W.beta + b.  NULL = no fold. */
+  const float *ln_stats;
+  const float *ln_colsum;
 } sp_gemm_desc;
 
 int sp_gemm_f16(const sp_gemm_desc *desc, void *stream);
@@ -125,6 +131,11 @@ int sp_groupnorm_f16(const void *x, const float *gamma, const float *beta, void 
 int sp_layernorm_f16(const void *x, const void *addvec, int64_t addvec_rows, void *sum_out,
                      const float *gamma, const float *beta, void *y, int64_t rows, int c, float eps,
                      void *stream);
+/* Statistics only, for a LayerNorm that is folded into the next GEMM (sp_gemm_desc.ln_stats): stats[row] = (mean,
+ * 1/sqrt(var + eps)) over the C channels of xin (same optional pre-add / sum_out as sp_layernorm_f16).  One read of
+ * x instead of a read and a write. */
+int sp_ln_stats_f16(const void *x, const void *addvec, int64_t addvec_rows, void *sum_out, float *stats,
+                    int64_t rows, int c, float eps, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention.  Replaces F.scaled_dot_product_attention / xformers (svd_unet.py:142) for

@@ -278,6 +278,38 @@ def test_groupnorm_large_mean_small_variance(inst, rows, c):
     check(y, ref)
 
 
+@pytest.mark.parametrize("m,c,n,geglu,route", [(1000, 320, 960, False, 0), (5000, 640, 1920, False, 2), (40000, 320, 2560, True, 3),
+                                               (2016, 1280, 3840, False, 0), (3000, 1280, 2560, True, 2), (700, 64, 128, True, 1),
+                                               (33000, 640, 1280, False, 3)])
+def test_gemm_with_folded_layernorm(m, c, n, geglu, route):
+    """LayerNorm folded into the next contraction (sp_ln_stats_f16 + sp_gemm_desc.ln_stats / ln_colsum): the GEMM
+    runs on the UN-normalised rows with gamma-scaled weights and applies rstd*(acc - mean*colsum) + (W.beta + b)
+    in its epilogue.  Every kernel family, rows with a large common offset; vs torch layer_norm -> linear (-> GEGLU)."""
+    ops = _ops()
+    from vdpp_amd.models.unet_hip import _Dense
+    g = torch.Generator().manual_seed(m + n)
+    x = h(torch.randn(m, c, generator=g) * 1.7 + 3.0 * torch.randn(m, 1, generator=g))
+    gamma = 1.0 + 0.3 * torch.randn(c, generator=g); beta = 0.5 * torch.randn(c, generator=g)
+    w = h(torch.randn(n, c, generator=g) / math.sqrt(c)); b = torch.randn(n, generator=g)
+    layer = _Dense.fold_layernorm(w, b, gamma, beta, DEV, eps=1e-5, geglu=geglu)
+    xd = x.half().to(DEV)
+    st = torch.empty(m, 2, device=DEV)
+    ops.ln_stats(xd, st, rows=m, c=c, eps=1e-5)
+    nout = n // 2 if geglu else n
+    out = torch.full((m + 2, nout), 7.0, dtype=torch.float16, device=DEV)
+    with ops.gemm_route(route):
+        ops.gemm(xd, layer.w, out[1:m + 1], m=m, n=n, cin=c, bias=layer.bias, geglu=geglu, ln_stats=st,
+                 ln_colsum=layer.colsum)
+    torch.cuda.synchronize()
+    assert torch.all(out[0] == 7.0) and torch.all(out[m + 1] == 7.0)
+    y = F.layer_norm(x, (c,), gamma, beta, eps=1e-5) @ w.t() + b
+    if geglu:
+        y = y[:, :nout] * F.gelu(y[:, nout:])
+    mu, var = x.mean(1), x.var(1, unbiased=False)
+    assert float((st[:, 0].cpu() - mu).abs().max()) < 2e-3 and rel_l2(st[:, 1].cpu(), (var + 1e-5).rsqrt()) < 1e-4
+    check(out[1:m + 1], y, l2=3e-3, mx=2e-2)
+
+
 @pytest.mark.parametrize("rows,c", [(100, 64), (1000, 320), (513, 640), (130, 1280)])
 def test_layernorm(rows, c):
     ops = _ops()

@@ -266,12 +266,18 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_f16_kernel(const GemmArgs
     for (int i = 0; i < TN; ++i) {
       const int nl = wn * WTN + i * 16 + 4 * fq;
       const int n = tile_n * BN + nl;
-      f32x4 b = {0.f, 0.f, 0.f, 0.f};
+      f32x4 b = {0.f, 0.f, 0.f, 0.f}, cs = b;
       if (p.bias) b = *(const f32x4 *)(p.bias + n);
+      if (p.ln_stats) cs = *(const f32x4 *)(p.ln_colsum + n);
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int ml = wm * WTM + j * 16 + fr;
         f32x4 v = acc[i][j] + b;
+        if (p.ln_stats) {       // folded LayerNorm: rstd*(acc - mean*colsum) + bias
+          const int64_t mm = min((int64_t)tile_m * BM + ml, (int64_t)p.m - 1);
+          const float2 st = *(const float2 *)(p.ln_stats + mm * 2);
+          v = (acc[i][j] - st.x * cs) * st.y + b;
+        }
         if (p.bias2) {
           const int64_t m = (int64_t)tile_m * BM + ml;
           const int64_t brow = m < p.m ? m / p.bias2_rows : 0;
@@ -288,16 +294,26 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_f16_kernel(const GemmArgs
       for (int i = 0; i < TN; i += 2) {
         const int nl = wn * WTN + i * 16 + 4 * fq;   // h rows; gate rows are nl + 16
         const int n = tile_n * BN + nl;
-        f32x4 bh = {0.f, 0.f, 0.f, 0.f}, bg = bh;
+        f32x4 bh = {0.f, 0.f, 0.f, 0.f}, bg = bh, ch = bh, cg = bh;
         if (p.bias) {
           bh = *(const f32x4 *)(p.bias + n);
           bg = *(const f32x4 *)(p.bias + n + 16);
+        }
+        if (p.ln_stats) {
+          ch = *(const f32x4 *)(p.ln_colsum + n);
+          cg = *(const f32x4 *)(p.ln_colsum + n + 16);
         }
         const int ol = (wn * WTN + i * 16) / 2 + 4 * fq;  // output column within tile
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
           const int ml = wm * WTM + j * 16 + fr;
-          const f32x4 hv = acc[i][j] + bh, gv = acc[i + 1][j] + bg;
+          f32x4 hv = acc[i][j] + bh, gv = acc[i + 1][j] + bg;
+          if (p.ln_stats) {
+            const int64_t mm = min((int64_t)tile_m * BM + ml, (int64_t)p.m - 1);
+            const float2 st = *(const float2 *)(p.ln_stats + mm * 2);
+            hv = (acc[i][j] - st.x * ch) * st.y + bh;
+            gv = (acc[i + 1][j] - st.x * cg) * st.y + bg;
+          }
           f16x4 h;
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[r] = (f16)(p.oscale * hv[r] * gelu_f(gv[r]));
@@ -458,6 +474,10 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
 #endif
   a.a = (const f16 *)d->a; a.w = (const f16 *)d->w; a.bias = d->bias; a.bias2 = d->bias2;
   a.res1 = (const f16 *)d->res1; a.res2 = (const f16 *)d->res2; a.d = (f16 *)d->d;
+  a.ln_stats = d->ln_stats; a.ln_colsum = d->ln_colsum;
+  if (d->ln_stats)
+    SP_REQUIRE(d->ln_colsum && d->mode == SP_A_LINEAR && !d->bias2,
+               "sp_gemm_f16: a folded LayerNorm needs ln_colsum, SP_A_LINEAR and no bias2");
   a.zero = (const char *)d->zero_page;
   a.lda = d->lda; a.ldr1 = d->ldr1; a.ldr2 = d->ldr2; a.ldd = d->ldd;
   a.mode = d->mode; a.cin = d->cin;

@@ -18,6 +18,8 @@ struct GemmArgs {
   const float *bias2;
   const f16 *res1;
   const f16 *res2;
+  const float *ln_stats;    // LayerNorm fold: fp32 [m][2] (mean, rstd), or null
+  const float *ln_colsum;   // fp32 [n]: row sums of the gamma-scaled weight
   f16 *d;
   const char *zero;
   int64_t lda, ldr1, ldr2, ldd, hw, bias2_rows, ldb2;

@@ -93,6 +93,26 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
     return ok ? res + m * ldr + col : (const f16 *)p.zero;
   };
 
+  // ---- folded LayerNorm: acc <- rstd[m]*(acc - mean[m]*colsum[n]) + bias[n] (the accumulators were started at zero)
+  if (p.ln_stats) {
+    f32x2 st[TM];
+    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.ln_stats, 0, (int)min((int64_t)p.m * 8, (int64_t)0x7fffffff), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < TM; ++j)       // (rows past M fall outside the buffer and read zeros; they are never stored)
+      st[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
+          s_rsrc, (int)((mbase + wm * WTM + j * 16 + fr) * 8), 0, 0));
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = tile_n * BN + wn * WTN + i * 16 + 4 * fq;
+      const f32x4 cs = *(const f32x4 *)(p.ln_colsum + n);
+      f32x4 b = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) b = *(const f32x4 *)(p.bias + n);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = (acc[i][j] - st[j][0] * cs) * st[j][1] + b;
+      __builtin_amdgcn_sched_barrier(0);      // one column sub-tile at a time (hoisting all row sums costs 40 registers)
+    }
+  }
   f16x8 q1[ITERS];
   if (p.res1) {
 #pragma unroll
@@ -376,7 +396,8 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     bias_v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias_v[i] = *(const f32x4 *)(p.bias + tile_n * BN + wn * WTN + i * 16 + 4 * (lane >> 4));
+    // (a folded LayerNorm applies its bias in the epilogue, after the row scaling)
+    if (p.bias && !p.ln_stats) bias_v[i] = *(const f32x4 *)(p.bias + tile_n * BN + wn * WTN + i * 16 + 4 * (lane >> 4));
   }
   __builtin_amdgcn_sched_barrier(0);
 

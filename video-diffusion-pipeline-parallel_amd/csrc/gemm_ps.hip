@@ -228,6 +228,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
       const float *b1 = p.bias ? p.bias + c0 : (const float *)p.zero;
       const float *b2 = (const float *)p.zero;
       if (p.bias2) b2 = p.bias2 + ((int64_t)(c_tm * BM) / p.bias2_rows) * p.ldb2 + c0;
+      if (p.ln_stats) b2 = p.ln_colsum + c0;        // folded LayerNorm: the second piece carries the weight's row sums
       glds16(b1, bias_lds);
       glds16(b2, bias_lds + 1024);
     }
@@ -299,6 +300,22 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
       const int col0 = c_tn * BNO + wn * WTNO + ocol;        // + pair*32
       uint4 q[TM][TNO / 2];                                  // residual pieces, then the packed output, in the FINAL
                                                              // layout (8 consecutive channels per lane)
+      // ---- folded LayerNorm: acc <- rstd[m]*(acc - mean[m]*colsum[n]); its bias is added below like any other
+      const bool ln = p.ln_stats != nullptr;
+      if (ln) {
+        f32x2 st[TM];
+        const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)p.ln_stats, 0, (int)min((int64_t)p.m * 8, (int64_t)0x7fffffff), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          st[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(s_rsrc, (int)((mrow0 + j * 16) * 8), 0, 0));
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const f32x4 cs = *(const f32x4 *)(bias_lds + 1024 + (i * 16 + 4 * fq) * 4);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = (acc[i][j] - st[j][0] * cs) * st[j][1];
+        }
+      }
       // ---- (acc + bias) * scale [GEGLU: value * gelu(gate)] -> va/vb kept in the accumulator registers
       const float osc = p.oscale;
 #pragma unroll
@@ -307,7 +324,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
 #pragma unroll
         for (int t = 0; t < (GEGLU ? 4 : 2); ++t) {
           const int i = (GEGLU ? 4 : 2) * o + t;
-          bs[t] = *(const f32x4 *)(bias_lds + (i * 16 + 4 * fq) * 4) + *(const f32x4 *)(bias_lds + 1024 + (i * 16 + 4 * fq) * 4);
+          bs[t] = *(const f32x4 *)(bias_lds + (i * 16 + 4 * fq) * 4);
+          if (!ln) bs[t] += *(const f32x4 *)(bias_lds + 1024 + (i * 16 + 4 * fq) * 4);
         }
 #pragma unroll
         for (int j = 0; j < TM; ++j) {

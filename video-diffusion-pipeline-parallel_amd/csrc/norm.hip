@@ -325,6 +325,49 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16 *__restrict__ x, cons
   }
 }
 
+// statistics only (LayerNorm folded into the next GEMM): same row walk as ln_kernel, writes (mean, rstd)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const f16 *__restrict__ x, const f16 *__restrict__ addvec,
+                                                       int64_t addvec_rows, f16 *__restrict__ sum_out,
+                                                       float *__restrict__ stats, int64_t rows, int c, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int oc = c >> 3;
+  float v[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int o = lane + i * 64;
+    if (o < oc) {
+      f16x8 q = *(const f16x8 *)(x + row * c + o * 8);
+      if (addvec) {
+        const f16x8 a = *(const f16x8 *)(addvec + (row / addvec_rows) * c + o * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = (f16)((float)q[e] + (float)a[e]);
+        if (sum_out) *(f16x8 *)(sum_out + row * c + o * 8) = q;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = (float)q[e]; s += v[i][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)c;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int o = lane + i * 64;
+    if (o < oc) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)c + eps);
+  if (lane == 0) *(float2 *)(stats + row * 2) = make_float2(mean, rstd);
+}
+
 }  // namespace
 
 extern "C" size_t sp_groupnorm_ws_bytes(int instances, int64_t rows, int c, int groups) {
@@ -402,5 +445,27 @@ extern "C" int sp_layernorm_f16(const void *x, const void *addvec, int64_t addve
   else LN_LAUNCH(4);
 #undef LN_LAUNCH
   SP_CHECK_LAUNCH("sp_layernorm_f16");
+  return SP_OK;
+}
+
+extern "C" int sp_ln_stats_f16(const void *x, const void *addvec, int64_t addvec_rows, void *sum_out, float *stats,
+                               int64_t rows, int c, float eps, void *stream) {
+  SP_REQUIRE(x && stats, "sp_ln_stats_f16: null pointer");
+  SP_REQUIRE(rows > 0 && c % 8 == 0 && c >= 8 && c <= 2048, "sp_ln_stats_f16: rows=%lld C=%d unsupported",
+             (long long)rows, c);
+  if (addvec) SP_REQUIRE(addvec_rows > 0, "sp_ln_stats_f16: addvec_rows must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  const int oc = c / 8;
+  SP_CLEAR_STALE_ERROR();
+#define LNS_LAUNCH(NV)                                                                                    \
+  hipLaunchKernelGGL(ln_stats_kernel<NV>, dim3(grid), dim3(256), 0, s, (const f16 *)x, (const f16 *)addvec, \
+                     addvec_rows > 0 ? addvec_rows : 1, (f16 *)sum_out, stats, rows, c, eps)
+  if (oc <= 64) LNS_LAUNCH(1);
+  else if (oc <= 128) LNS_LAUNCH(2);
+  else if (oc <= 192) LNS_LAUNCH(3);
+  else LNS_LAUNCH(4);
+#undef LNS_LAUNCH
+  SP_CHECK_LAUNCH("sp_ln_stats_f16");
   return SP_OK;
 }

@@ -29,6 +29,7 @@ class GemmDesc(ctypes.Structure):
         ("res2", ctypes.c_void_p), ("ldr2", ctypes.c_int64), ("r2scale", ctypes.c_float),
         ("oscale", ctypes.c_float), ("geglu", ctypes.c_int), ("n_store", ctypes.c_int),
         ("d", ctypes.c_void_p), ("ldd", ctypes.c_int64), ("zero_page", ctypes.c_void_p),
+        ("ln_stats", ctypes.c_void_p), ("ln_colsum", ctypes.c_void_p),
     ]
 
 
@@ -45,6 +46,7 @@ SIGNATURES = {
     "sp_groupnorm_ws_bytes": (_Z, [_I, _L, _I, _I]),
     "sp_groupnorm_f16": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _Z, _P]),
     "sp_layernorm_f16": (_I, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _F, _P]),
+    "sp_ln_stats_f16": (_I, [_P, _P, _L, _P, _P, _L, _I, _F, _P]),
     "sp_attn_spatial_f16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _P]),
     "sp_attn_fp8_ws_bytes": (_L, [_I, _I, _I]),
     "sp_attn_spatial_fp8": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _L, _P, _P]),

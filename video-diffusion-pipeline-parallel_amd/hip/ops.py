@@ -81,8 +81,9 @@ def _rows(t: torch.Tensor, name: str, ld: int) -> torch.Tensor:
 
 def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=None, bias=None,
          bias2=None, bias2_rows=0, ldb2=0, res1=None, r1scale=1.0, res2=None, r2scale=1.0, oscale=1.0,
-         geglu=False, n_store=0, ldd=None, ldr1=None, ldr2=None):
-    """``out[m][:] = epilogue(sum_taps A_tap @ W^T)``; see ``sp_gemm_desc`` in include/svdpipe.h."""
+         geglu=False, n_store=0, ldd=None, ldr1=None, ldr2=None, ln_stats=None, ln_colsum=None):
+    """``out[m][:] = epilogue(sum_taps A_tap @ W^T)``; see ``sp_gemm_desc`` in include/svdpipe.h.
+    ``ln_stats`` / ``ln_colsum``: LayerNorm folded into the contraction (``a`` is the UN-normalised tensor)."""
     d = GemmDesc()
     d.lda = int(lda if lda is not None else cin)
     d.a, d.mode, d.cin = _rows(a, "a", d.lda).data_ptr(), mode, cin
@@ -99,6 +100,7 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
     d.ldd = int(ldd if ldd is not None else (n_store or nout))
     d.d = _rows(out, "out", d.ldd).data_ptr()
     d.zero_page = zero_page(a.device).data_ptr()
+    d.ln_stats, d.ln_colsum = _ptr(ln_stats), _ptr(ln_colsum)
     taps = 9 if mode == A_CONV3X3 else 3 if mode == A_TEMPORAL3 else 1
     # algorithmic bytes of this launch: every operand element once (A without tap re-reads), output and residuals once
     a_rows = d.n_img * d.hin * d.win if mode == A_CONV3X3 else m
@@ -162,6 +164,13 @@ def layernorm(x, gamma, beta, y, *, rows, c, eps=1e-5, addvec=None, addvec_rows=
                                    gamma.data_ptr(), beta.data_ptr(), _f16(y, "y").data_ptr(), rows, c, eps,
                                    _stream()), "sp_layernorm_f16")
     return y
+
+
+def ln_stats(x, stats, *, rows, c, eps=1e-5, addvec=None, addvec_rows=0, sum_out=None):
+    """Per-row (mean, rstd) of a LayerNorm that the next GEMM applies itself (``gemm(..., ln_stats=, ln_colsum=)``)."""
+    _check(load().sp_ln_stats_f16(_f16(x, "x").data_ptr(), _ptr(addvec), addvec_rows, _ptr(sum_out), stats.data_ptr(),
+                                  rows, c, eps, _stream()), "sp_ln_stats_f16")
+    return stats
 
 
 def attn_spatial(q, k, v, o, *, ldq, ldk, ldv, ldo, batch, seq, heads, scale=0.125):

@@ -47,11 +47,25 @@ def _f32(t, device):
 class _Dense:
     """One contraction: packed fp16 weight ``[N][K]`` + fp32 bias, and how its A operand is gathered."""
 
-    def __init__(self, w16, bias32, *, cin, mode=ops.A_LINEAR, n_true=None, geglu=False):
+    def __init__(self, w16, bias32, *, cin, mode=ops.A_LINEAR, n_true=None, geglu=False, colsum=None, ln_eps=None):
         self.w, self.bias, self.cin, self.mode = w16, bias32, cin, mode
         self.n = w16.shape[0]
         self.n_true = n_true if n_true is not None else (self.n // 2 if geglu else self.n)
         self.geglu = geglu
+        self.colsum, self.ln_eps = colsum, ln_eps          # set when a LayerNorm is folded into this contraction
+
+    @staticmethod
+    def fold_layernorm(w, b, norm_w, norm_b, dev, *, eps, geglu=False):
+        """``LN(x) @ W^T + b`` as a contraction on the un-normalised x: ``rstd*(x @ (W*gamma)^T - mean*colsum) + (W @ beta
+        + b)`` with ``colsum[n] = sum_k (W*gamma)[n][k]`` taken over the fp16 values the kernel multiplies with."""
+        w32, g32, be32 = w.to(dev).float(), norm_w.to(dev).float(), norm_b.to(dev).float()
+        bias = w32 @ be32 + (b.to(dev).float() if b is not None else 0.0)
+        wg = (w32 * g32[None, :])
+        if geglu:
+            wg, bias = W.interleave_geglu(wg, bias)
+        wg16 = wg.to(torch.float16).contiguous()
+        return _Dense(wg16, bias.float().contiguous(), cin=wg16.shape[1], geglu=geglu,
+                      colsum=wg16.float().sum(dim=1).contiguous(), ln_eps=eps)
 
     @staticmethod
     def linear(sd, p, dev, bias=True):
@@ -197,10 +211,15 @@ class SVDUNetHIP:
             tn2=_Norm(sd, t + ".norm2", dev, eps), tc2=_Dense.tconv(sd, t + ".conv2", dev),
         )
 
-    def _attn(self, sd, p, dev):
+    def _attn(self, sd, p, dev, norm):
+        """``norm``: state_dict prefix of the LayerNorm in front of the Q/K/V projections (folded into them)."""
         qkv = torch.cat([sd[p + ".to_q.weight"], sd[p + ".to_k.weight"], sd[p + ".to_v.weight"]], dim=0)
-        w = W.pack_linear(qkv).to(dev)
-        return dict(qkv=_Dense(w, None, cin=w.shape[1]), out=_Dense.linear(sd, p + ".to_out.0", dev))
+        return dict(qkv=_Dense.fold_layernorm(qkv, None, sd[norm + ".weight"], sd[norm + ".bias"], dev, eps=1e-5),
+                    out=_Dense.linear(sd, p + ".to_out.0", dev))
+
+    def _geglu_ln(self, sd, p, dev, norm):
+        return _Dense.fold_layernorm(sd[p + ".weight"], sd[p + ".bias"], sd[norm + ".weight"], sd[norm + ".bias"], dev,
+                                     eps=1e-5, geglu=True)
 
     def _xattn(self, sd, p, dev):
         return dict(v=W.pack_linear(sd[p + ".to_v.weight"]).to(dev), o=W.pack_linear(sd[p + ".to_out.0.weight"]).to(dev),
@@ -266,15 +285,16 @@ class SVDUNetHIP:
             pout=_Dense.linear(sd, p + ".proj_out", dev),
             pe1=_Dense.linear(sd, p + ".time_pos_embed.linear_1", dev),
             pe2=_Dense.linear(sd, p + ".time_pos_embed.linear_2", dev),
-            s_n1=_Norm(sd, b + ".norm1", dev, 1e-5), s_attn=self._attn(sd, b + ".attn1", dev),
+            # the five LayerNorms of a transformer sit in front of a Q/K/V or GEGLU projection and are folded into it
+            s_attn=self._attn(sd, b + ".attn1", dev, b + ".norm1"),
             s_x=self._xattn(sd, b + ".attn2", dev),
-            s_n3=_Norm(sd, b + ".norm3", dev, 1e-5), s_ff1=_Dense.geglu_proj(sd, b + ".ff.net.0.proj", dev),
+            s_ff1=self._geglu_ln(sd, b + ".ff.net.0.proj", dev, b + ".norm3"),
             s_ff2=_Dense.linear(sd, b + ".ff.net.2", dev),
-            t_nin=_Norm(sd, t + ".norm_in", dev, 1e-5), t_fi1=_Dense.geglu_proj(sd, t + ".ff_in.net.0.proj", dev),
+            t_fi1=self._geglu_ln(sd, t + ".ff_in.net.0.proj", dev, t + ".norm_in"),
             t_fi2=_Dense.linear(sd, t + ".ff_in.net.2", dev),
-            t_n1=_Norm(sd, t + ".norm1", dev, 1e-5), t_attn=self._attn(sd, t + ".attn1", dev),
+            t_attn=self._attn(sd, t + ".attn1", dev, t + ".norm1"),
             t_x=self._xattn(sd, t + ".attn2", dev),
-            t_n3=_Norm(sd, t + ".norm3", dev, 1e-5), t_ff1=_Dense.geglu_proj(sd, t + ".ff.net.0.proj", dev),
+            t_ff1=self._geglu_ln(sd, t + ".ff.net.0.proj", dev, t + ".norm3"),
             t_ff2=_Dense.linear(sd, t + ".ff.net.2", dev),
         )
 
@@ -289,9 +309,18 @@ class SVDUNetHIP:
             out = self._buf(m, layer.n_true)
         n_store = layer.n_true if (layer.n_true != (layer.n // 2 if layer.geglu else layer.n)) else 0
         temporal = (r.f, r.hw) if layer.mode == ops.A_TEMPORAL3 else None
+        if layer.colsum is not None and "ln_stats" not in kw:
+            raise RuntimeError("this contraction carries a folded LayerNorm: pass ln_stats")
         ops.gemm(a, layer.w, out, m=m, n=layer.n, cin=layer.cin, mode=layer.mode, conv=conv, temporal=temporal,
-                 bias=layer.bias, geglu=layer.geglu, n_store=n_store, ldd=layer.n_true, lda=a.shape[1], **kw)
+                 bias=layer.bias, geglu=layer.geglu, n_store=n_store, ldd=layer.n_true, lda=a.shape[1],
+                 ln_colsum=layer.colsum, **kw)
         return out
+
+    def _ln_stats(self, layer: _Dense, x, **kw):
+        """(mean, rstd) per row of x for the LayerNorm folded into ``layer``."""
+        st = torch.empty((x.shape[0], 2), dtype=torch.float32, device=self.device)
+        ops.ln_stats(x, st, rows=x.shape[0], c=x.shape[1], eps=layer.ln_eps, **kw)
+        return st
 
     def _gn(self, r: _Run, norm: _Norm, x, *, temporal: bool, silu: bool):
         c = x.shape[1]
@@ -331,10 +360,11 @@ class SVDUNetHIP:
         c, g = x["grp"]
         return r.cross[c][g]
 
-    def _self_attn(self, r: _Run, att, xvec, n_in, resid, *, temporal: bool, **epi):
+    def _self_attn(self, r: _Run, att, xvec, resid, *, temporal: bool, **epi):
+        """LayerNorm (folded into the fused Q/K/V projection) -> self-attention -> output projection + residual."""
         c = att["out"].n
         heads = c // 64
-        qkv = self._gemm(r, att["qkv"], n_in)
+        qkv = self._gemm(r, att["qkv"], resid, ln_stats=self._ln_stats(att["qkv"], resid))
         o = self._buf(r.m, c)
         q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
         if temporal:
@@ -360,8 +390,8 @@ class SVDUNetHIP:
         t = self._gn(r, p["norm"], x, temporal=False, silu=False)
         hs = self._gemm(r, p["pin"], t)
         # --- spatial block
-        hs1 = self._self_attn(r, p["s_attn"], p["s_x"], self._ln(p["s_n1"], hs), hs, temporal=False)
-        g = self._gemm(r, p["s_ff1"], self._ln(p["s_n3"], hs1))
+        hs1 = self._self_attn(r, p["s_attn"], p["s_x"], hs, temporal=False)
+        g = self._gemm(r, p["s_ff1"], hs1, ln_stats=self._ln_stats(p["s_ff1"], hs1))
         hs_s = self._gemm(r, p["s_ff2"], g, res1=hs1, r1scale=1.0)
         del g
         # --- frame positional embedding (B*F rows)
@@ -370,12 +400,12 @@ class SVDUNetHIP:
             pe = pe.repeat(r.b, 1)
         # --- temporal block on hmix = hs_s + pe[frame]
         hmix = self._buf(r.m, c)
-        nin = self._ln(p["t_nin"], hs_s, addvec=pe, addvec_rows=r.hw, sum_out=hmix)
-        g = self._gemm(r, p["t_fi1"], nin)
+        st = self._ln_stats(p["t_fi1"], hs_s, addvec=pe, addvec_rows=r.hw, sum_out=hmix)   # also writes hmix = hs_s + pe
+        g = self._gemm(r, p["t_fi1"], hmix, ln_stats=st)
         ht = self._gemm(r, p["t_fi2"], g, res1=hmix, r1scale=1.0)
-        del g, hmix, nin
-        ht1 = self._self_attn(r, p["t_attn"], p["t_x"], self._ln(p["t_n1"], ht), ht, temporal=True)
-        g = self._gemm(r, p["t_ff1"], self._ln(p["t_n3"], ht1))
+        del g, hmix, st
+        ht1 = self._self_attn(r, p["t_attn"], p["t_x"], ht, temporal=True)
+        g = self._gemm(r, p["t_ff1"], ht1, ln_stats=self._ln_stats(p["t_ff1"], ht1))
         # temporal out = ff(..)+ht1 ; blend = a*hs_s + (1-a)*temporal out   (folded into the epilogue)
         mix = self._gemm(r, p["t_ff2"], g, oscale=1.0 - a, res1=ht1, r1scale=1.0 - a, res2=hs_s, r2scale=a)
         del g
