@@ -44,18 +44,19 @@ for k in names:
     if ms < 0.05: continue
     print(f"{k:48s} {int(m['n']):5d} {ms:8.2f} {rd:8.2f} {wr:8.2f} {tb:9.2f} {busy:9.3f} {wait:6.2f}")
 
-# --- fold the implicit-GEMM rows for bench.py's roofline.traffic (argv[2] = output json, optional)
+# --- fold the implicit-GEMM rows for bench.py's roofline.traffic (argv[2] = output json, argv[3] = commit; optional)
 if len(sys.argv) > 2:
     import json
     rd = wr = n = 0.0
     for k in names:
-        if "gemm_pp_kernel" in k or "gemm_f16_kernel" in k:
+        if "gemm_pp_kernel" in k or "gemm_f16_kernel" in k or "gemm_ps_kernel" in k:
             rd += 2 * tables["fetch"][k]["FETCH_SIZE"] * 1024
             wr += tables["write"][k]["WRITE_SIZE"] * 1024
             n += tables["fetch"][k]["n"]
     json.dump({"source": "tools/pmc_forward.sh + tools/pmc_forward_summary.py (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                          "passes over the two UNet forwards of tools/one_forward.py = second half of the dispatches)",
-               "kernel": "implicit-GEMM kernels (gemm_pp_kernel<*>, gemm_f16_kernel<*>)",
+               "kernel": "implicit-GEMM kernels (gemm_pp_kernel<*>, gemm_ps_kernel<*>, gemm_f16_kernel<*>)",
+               "commit": sys.argv[3] if len(sys.argv) > 3 else "unknown",
                "fabric_read_bytes": rd, "write_bytes": wr, "launches": int(n),
                "note": "read bytes = 2 x FETCH_SIZE (gfx950 half-count correction), Infinity-Cache hits included"},
               open(sys.argv[2], "w"), indent=1)

@@ -11,7 +11,8 @@
 //    output channels of one row, adds bias / residuals in fp32 (one rounding) and writes 16 bytes; a wave
 //    instruction covers 16 rows x 64 contiguous bytes, which the memory system absorbs at the rate of whole-row
 //    stores (tools/store_probe.hip: 5.6-6.1 vs 6.0-6.4 TB/s chip-wide).
-//  * Bias vectors arrive by LDS-DMA as well (two 1-KiB pieces per wave per tile, read back with ds_read), so no
+//  * Bias vectors (and a folded LayerNorm's row sums / row statistics) arrive by LDS-DMA as well (three 1-KiB pieces
+//    per wave per tile, read back with ds_read), so no
 //    ordinary load sits in front of the stream: hipcc drains vmcnt to 0 before the first use of a VGPR load while
 //    LDS-DMA is in flight.
 //  * vmcnt bookkeeping.  LDS-DMA, loads and stores retire in issue order, so "K-step g+1 has landed" =
@@ -41,7 +42,7 @@ __device__ long long g_ps_steps[PS_TRACE_WGS * 2 * PS_STEP_SLOTS];
 #define PS_STEP(idx)                                                                                     \
   do {                                                                                                   \
     if (ps_tile == 1 && (tid == 0 || tid == 256) && (idx) < PS_STEP_SLOTS)                               \
-      ((long long *)(smem + RING + 8 * 2048))[(tid ? PS_STEP_SLOTS : 0) + (idx)] = PS_NOW();             \
+      ((long long *)(smem + RING + 8 * 3072))[(tid ? PS_STEP_SLOTS : 0) + (idx)] = PS_NOW();             \
   } while (0)
 #else
 #define PS_STEP(idx) do {} while (0)
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
   static_assert((A_SPLIT == 8 || A_SPLIT == 4) && (B_SPLIT == 8 || B_SPLIT == 4), "wave halves must have uniform DMA counts");
   constexpr int L_EARLY = A_LOADS + B_LOADS;
   constexpr int L_LATE = (A_SPLIT == 8 ? A_LOADS : A_LOADS_HI) + (B_SPLIT == 8 ? B_LOADS : B_LOADS_HI);
-  constexpr int NBIAS = 2;                                 // bias pieces per wave per tile (bias, bias2 row)
+  constexpr int NBIAS = 3;                                 // 1-KiB side pieces per wave per tile: bias, bias2 row / LayerNorm
+                                                           // row sums, LayerNorm (mean, rstd) of the wave's rows
   static_assert(2 * L_EARLY + NSTORE + NBIAS < 64, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef SP_GEMM_EXPERIMENTS
@@ -229,8 +231,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
       const float *b2 = (const float *)p.zero;
       if (p.bias2) b2 = p.bias2 + ((int64_t)(c_tm * BM) / p.bias2_rows) * p.ldb2 + c0;
       if (p.ln_stats) b2 = p.ln_colsum + c0;        // folded LayerNorm: the second piece carries the weight's row sums
+      const char *b3 = p.zero;
+      if (p.ln_stats)   // (mean, rstd) of this wave's WTM rows: 8 bytes per row, two rows per lane; clamped at the last row pair
+        b3 = (const char *)p.ln_stats + min(((int64_t)c_tm * BM + wm * WTM) * 8 + lane * 16, (int64_t)p.m * 8 - 16);
       glds16(b1, bias_lds);
       glds16(b2, bias_lds + 1024);
+      glds16(b3, bias_lds + 2048);
     }
     if (issue) stage();
     if (late) wait_stream<L_LATE, NBIAS, NSTORE + NBIAS>(young, xk);
@@ -304,11 +310,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
       const bool ln = p.ln_stats != nullptr;
       if (ln) {
         f32x2 st[TM];
-        const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)p.ln_stats, 0, (int)min((int64_t)p.m * 8, (int64_t)0x7fffffff), 0x00020000);
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
-          st[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(s_rsrc, (int)((mrow0 + j * 16) * 8), 0, 0));
+        for (int j = 0; j < TM; ++j) st[j] = *(const f32x2 *)(bias_lds + 2048 + (j * 16 + fr) * 8);
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
           const f32x4 cs = *(const f32x4 *)(bias_lds + 1024 + (i * 16 + 4 * fq) * 4);
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
 #ifdef SP_GEMM_EXPERIMENTS
   if ((tid == 0 || tid == 256) && blockIdx.x < PS_TRACE_WGS) {
     for (int i = 0; i < PS_STEP_SLOTS; ++i)
-      g_ps_steps[(blockIdx.x * 2 + (tid ? 1 : 0)) * PS_STEP_SLOTS + i] = ((long long *)(smem + RING + 8 * 2048))[(tid ? PS_STEP_SLOTS : 0) + i];
+      g_ps_steps[(blockIdx.x * 2 + (tid ? 1 : 0)) * PS_STEP_SLOTS + i] = ((long long *)(smem + RING + 8 * 3072))[(tid ? PS_STEP_SLOTS : 0) + i];
     long long *t = g_ps_trace + blockIdx.x * PS_TRACE_SLOTS + (tid ? 8 : 0);
     t[0] = ps_start; t[1] = ps_first; t[2] = ps_loop; t[3] = ps_align; t[4] = ps_epi; t[5] = PS_NOW(); t[6] = nmy;
   }
@@ -405,9 +408,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
 template <int BM, int BN, int WM, int WN, bool GEGLU>
 int launch_ps_t(GemmArgs &a, hipStream_t s) {
 #ifdef SP_GEMM_EXPERIMENTS
-  constexpr size_t lds = (size_t)SSTAGES * (BM + BN) * 64 + 8 * 2048 + 1024;   // + per-K-step stamps
+  constexpr size_t lds = (size_t)SSTAGES * (BM + BN) * 64 + 8 * 3072 + 1024;   // + per-K-step stamps
 #else
-  constexpr size_t lds = (size_t)SSTAGES * (BM + BN) * 64 + 8 * 2048;
+  constexpr size_t lds = (size_t)SSTAGES * (BM + BN) * 64 + 8 * 3072;
 #endif
   static_assert(lds <= 160 * 1024, "LDS per workgroup");
   static bool attr_set[SP_MAX_DEVICES] = {};
