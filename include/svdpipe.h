@@ -84,6 +84,17 @@ typedef struct sp_gemm_desc {
      values), bias[n] = W.beta + b.  NULL = no fold. */
   const float *ln_stats;
   const float *ln_colsum;
+  /* Guidance mix + Euler update folded into the epilogue of the UNet's last convolution (conv_out: n = 64 padded
+     weight rows of which 4 are real; /root/reference/src/models/svd_unet.py:410-439).  euler_out != NULL: instead of
+     storing eps rows in d, row m = (b, f, pixel) updates the four latent channels
+       eps = euler_eps_uncond ? u + g[f]*(eps - u) (evaluated in fp16 like the reference) : eps
+       x0 = eps*(-sigma/sqrt(sigma^2+1)) + x/(sigma^2+1);  x' = x + (x - x0)/sigma*(sigma_next - sigma)   (fp32)
+     with x read from euler_latent and x' written to euler_out, both fp16 (B,4,F,H,W); d is not written. */
+  const void *euler_latent; void *euler_out;
+  const void *euler_eps_uncond; int64_t euler_ld_eps;   /* fp16 [m][euler_ld_eps] eps rows of the unconditional pass, or NULL */
+  const float *euler_guidance;                         /* fp32 [frames] per-frame guidance scale (with euler_eps_uncond) */
+  float euler_sigma, euler_sigma_next;
+  int euler_frames; int64_t euler_hw;                  /* m = b*frames*hw + f*hw + pixel */
 } sp_gemm_desc;
 
 int sp_gemm_f16(const sp_gemm_desc *desc, void *stream);

@@ -226,6 +226,36 @@ def test_batched_cfg_equals_sequential_cfg():
     assert rel_l2(b.float(), a.float().cpu()) <= 1e-3
 
 
+@pytest.mark.parametrize("guidance", [None, 2.5])
+def test_euler_tail_in_conv_out_epilogue_is_bit_identical(guidance):
+    """the guidance mix + Euler update run in the epilogue of the UNet's last convolution (no eps rows in
+    HBM, no separate launch).  Same arithmetic and roundings as sp_euler_step_f16 on stored eps rows -> the new latent
+    is bit-identical to the two-kernel path (ref svd_unet.py:410-439)."""
+    from vdpp_amd.hip import ops
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+
+    cfg, sd, ref, hip = _build(seed=31)
+    model = StableVideoUNet(unet=hip, timesteps=StableVideoUNet._default_timestep_schedule(25))
+    g = torch.Generator().manual_seed(12)
+    frames, h, w = 3, 16, 24
+    emb = torch.randn(1, 1, cfg.cross_attention_dim, generator=g).half().to(DEV)
+    img = torch.randn(1, 4, frames, h, w, generator=g).half().to(DEV)
+    model.set_conditioning(emb, img, guidance_scale=guidance, num_frames=frames)
+    lat = (torch.randn(1, 4, frames, h, w, generator=g) * 30).half().to(DEV)
+    for step in (0, 11, 24):
+        fused = model(lat, step)
+        sigma, sigma_next = model._sigma_host[step], model._sigma_host[step + 1]
+        in_scale = 1.0 / (sigma * sigma + 1.0) ** 0.5
+        eps_u = None
+        if guidance:
+            eps_u = model._unet_pass(lat, model._uncond_image_latents, model._uncond_embeddings, in_scale, step)
+        eps_c = model._unet_pass(lat, model._image_latents, model._image_embeddings, in_scale, step)
+        want = torch.empty_like(lat)
+        ops.euler_step(lat, eps_c, eps_u, model._guidance32 if guidance else None, want, ld_eps=eps_c.shape[1],
+                       sigma=sigma, sigma_next=sigma_next, b=1, frames=frames, h=h, w=w)
+        assert torch.equal(fused, want), f"step {step}"
+
+
 def test_graph_replay_equals_eager():
     """HIP-graph replay of a step (capture once, replay with new latents) is bit-identical to eager launches."""
     from vdpp_amd.models.svd_unet import StableVideoUNet

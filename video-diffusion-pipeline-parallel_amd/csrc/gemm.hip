@@ -334,6 +334,33 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_f16_kernel(const GemmArgs
     const int col = tile_n * bno + c * 8;
     if (col >= nstore) continue;
     f16x8 v = *(const f16x8 *)(sc + r * ldc + c * 8);
+    if (p.eul_out) {
+      // guidance mix + Euler update of the four latent channels of row m = (b, f, pixel) (same arithmetic, same
+      // roundings as sp_euler_step_f16 on the eps rows this epilogue would otherwise have written)
+      if (col != 0) continue;
+      const int64_t pix = m % p.eul_hw, bf = m / p.eul_hw;
+      const int f = (int)(bf % p.eul_frames);
+      const int64_t b = bf / p.eul_frames;
+      f16x4 u4 = {v[0], v[1], v[2], v[3]};
+      float g = 1.f;
+      if (p.eul_u) { u4 = *(const f16x4 *)(p.eul_u + m * p.eul_ldu); g = p.eul_gs[f]; }
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        const int64_t a = ((b * 4 + ch) * p.eul_frames + f) * p.eul_hw + pix;
+        const float x = (float)p.eul_lat[a];
+        float e = (float)v[ch];
+        if (p.eul_u) {
+          const f16 gh = (f16)g;
+          const f16 diff = (f16)((float)v[ch] - (float)u4[ch]);
+          const f16 prod = (f16)((float)gh * (float)diff);
+          e = (float)(f16)((float)u4[ch] + (float)prod);
+        }
+        const float x0 = e * p.eul_c_out + x * p.eul_c_skip;
+        const float d = (x - x0) * p.eul_inv_sigma;
+        p.eul_out[a] = (f16)(x + d * p.eul_dt);
+      }
+      continue;
+    }
     if (p.res1 || p.res2) {
       float f[8];
 #pragma unroll
@@ -475,6 +502,21 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   a.a = (const f16 *)d->a; a.w = (const f16 *)d->w; a.bias = d->bias; a.bias2 = d->bias2;
   a.res1 = (const f16 *)d->res1; a.res2 = (const f16 *)d->res2; a.d = (f16 *)d->d;
   a.ln_stats = d->ln_stats; a.ln_colsum = d->ln_colsum;
+  if (d->euler_out) {
+    SP_REQUIRE(d->euler_latent && d->n == 64 && d->n_store == 4 && !d->geglu && !d->res1 && !d->res2 && d->oscale == 1.0f,
+               "sp_gemm_f16: the Euler tail belongs to conv_out (n = 64, n_store = 4, no residuals, oscale 1)");
+    SP_REQUIRE(d->euler_frames > 0 && d->euler_hw > 0 && d->m % (d->euler_frames * d->euler_hw) == 0 && d->euler_sigma > 0.f,
+               "sp_gemm_f16: Euler tail: m=%d frames=%d hw=%lld sigma=%g", d->m, d->euler_frames, (long long)d->euler_hw,
+               (double)d->euler_sigma);
+    if (d->euler_eps_uncond) SP_REQUIRE(d->euler_guidance && d->euler_ld_eps >= 4 && d->euler_ld_eps % 4 == 0,
+                                        "sp_gemm_f16: Euler tail: guidance needs euler_guidance and euler_ld_eps");
+    const float s2 = d->euler_sigma * d->euler_sigma + 1.0f;
+    a.eul_lat = (const f16 *)d->euler_latent; a.eul_out = (f16 *)d->euler_out;
+    a.eul_u = (const f16 *)d->euler_eps_uncond; a.eul_gs = d->euler_guidance; a.eul_ldu = d->euler_ld_eps;
+    a.eul_frames = d->euler_frames; a.eul_hw = d->euler_hw;
+    a.eul_c_out = -d->euler_sigma / sqrtf(s2); a.eul_c_skip = 1.0f / s2;
+    a.eul_inv_sigma = 1.0f / d->euler_sigma; a.eul_dt = d->euler_sigma_next - d->euler_sigma;
+  }
   if (d->ln_stats)
     SP_REQUIRE(d->ln_colsum && d->mode == SP_A_LINEAR && !d->bias2,
                "sp_gemm_f16: a folded LayerNorm needs ln_colsum, SP_A_LINEAR and no bias2");

@@ -18,6 +18,11 @@ struct GemmArgs {
   const float *bias2;
   const f16 *res1;
   const f16 *res2;
+  // Euler tail (conv_out only): latent in / out (B,4,F,H,W) fp16, optional unconditional eps rows + per-frame guidance
+  const f16 *eul_lat; f16 *eul_out; const f16 *eul_u; const float *eul_gs;
+  int64_t eul_ldu, eul_hw;
+  int eul_frames;
+  float eul_c_out, eul_c_skip, eul_inv_sigma, eul_dt;
   const float *ln_stats;    // LayerNorm fold: fp32 [m][2] (mean, rstd), or null
   const float *ln_colsum;   // fp32 [n]: row sums of the gamma-scaled weight
   f16 *d;

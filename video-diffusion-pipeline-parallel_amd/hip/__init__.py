@@ -30,6 +30,11 @@ class GemmDesc(ctypes.Structure):
         ("oscale", ctypes.c_float), ("geglu", ctypes.c_int), ("n_store", ctypes.c_int),
         ("d", ctypes.c_void_p), ("ldd", ctypes.c_int64), ("zero_page", ctypes.c_void_p),
         ("ln_stats", ctypes.c_void_p), ("ln_colsum", ctypes.c_void_p),
+        ("euler_latent", ctypes.c_void_p), ("euler_out", ctypes.c_void_p),
+        ("euler_eps_uncond", ctypes.c_void_p), ("euler_ld_eps", ctypes.c_int64),
+        ("euler_guidance", ctypes.c_void_p),
+        ("euler_sigma", ctypes.c_float), ("euler_sigma_next", ctypes.c_float),
+        ("euler_frames", ctypes.c_int), ("euler_hw", ctypes.c_int64),
     ]
 
 

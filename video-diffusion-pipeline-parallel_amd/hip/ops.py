@@ -81,7 +81,7 @@ def _rows(t: torch.Tensor, name: str, ld: int) -> torch.Tensor:
 
 def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=None, bias=None,
          bias2=None, bias2_rows=0, ldb2=0, res1=None, r1scale=1.0, res2=None, r2scale=1.0, oscale=1.0,
-         geglu=False, n_store=0, ldd=None, ldr1=None, ldr2=None, ln_stats=None, ln_colsum=None):
+         geglu=False, n_store=0, ldd=None, ldr1=None, ldr2=None, ln_stats=None, ln_colsum=None, euler=None):
     """``out[m][:] = epilogue(sum_taps A_tap @ W^T)``; see ``sp_gemm_desc`` in include/svdpipe.h.
     ``ln_stats`` / ``ln_colsum``: LayerNorm folded into the contraction (``a`` is the UN-normalised tensor)."""
     d = GemmDesc()
@@ -101,6 +101,12 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
     d.d = _rows(out, "out", d.ldd).data_ptr()
     d.zero_page = zero_page(a.device).data_ptr()
     d.ln_stats, d.ln_colsum = _ptr(ln_stats), _ptr(ln_colsum)
+    if euler is not None:       # conv_out only: guidance mix + Euler update instead of storing eps rows (see svdpipe.h)
+        d.euler_latent, d.euler_out = _f16(euler["latent"], "latent").data_ptr(), _f16(euler["out"], "out").data_ptr()
+        d.euler_eps_uncond, d.euler_guidance = _ptr(euler.get("eps_uncond")), _ptr(euler.get("guidance"))
+        d.euler_ld_eps = int(euler.get("ld_eps", 0))
+        d.euler_sigma, d.euler_sigma_next = float(euler["sigma"]), float(euler["sigma_next"])
+        d.euler_frames, d.euler_hw = int(euler["frames"]), int(euler["hw"])
     taps = 9 if mode == A_CONV3X3 else 3 if mode == A_TEMPORAL3 else 1
     # algorithmic bytes of this launch: every operand element once (A without tap re-reads), output and residuals once
     a_rows = d.n_img * d.hin * d.win if mode == A_CONV3X3 else m

@@ -243,7 +243,7 @@ class StableVideoUNet(nn.Module):
         self._graphs.clear()
 
     # ------------------------------------------------------------------ one diffusion step
-    def _unet_pass(self, latent, image_latents, embeddings, in_scale, step):
+    def _unet_pass(self, latent, image_latents, embeddings, in_scale, step, euler=None):
         from ..hip import ops
 
         b, _, f, h, w = latent.shape
@@ -251,7 +251,7 @@ class StableVideoUNet(nn.Module):
         ops.pack_input(latent, image_latents, rows, in_scale=in_scale, b=b, frames=f, h=h, w=w,
                        cpad=self.unet.cin_pad)
         return self.unet.forward_rows(rows, b=b, frames=f, h=h, w=w, t_value=self._t_dev[step:step + 1],
-                                      ctx16=embeddings.reshape(b, -1), added_ids32=self._added_ids32)
+                                      ctx16=embeddings.reshape(b, -1), added_ids32=self._added_ids32, euler=euler)
 
     @torch.inference_mode()
     def forward(self, latent: torch.Tensor, step: int) -> torch.Tensor:
@@ -330,9 +330,15 @@ class StableVideoUNet(nn.Module):
             half = both.shape[0] // 2
             eps_u, eps_c = both[:half], both[half:]
         else:
+            # sequential passes (the reference's order): the conditional pass' last convolution applies the guidance
+            # mix and the Euler update in its epilogue, so its eps rows never exist in HBM
+            out = torch.empty_like(latent)
+            tail = dict(latent=latent, out=out, sigma=sigma, sigma_next=sigma_next)
             if guided:
                 eps_u = self._unet_pass(latent, self._uncond_image_latents, self._uncond_embeddings, in_scale, step)
-            eps_c = self._unet_pass(latent, self._image_latents, self._image_embeddings, in_scale, step)
+                tail.update(eps_uncond=eps_u, guidance=self._guidance32, ld_eps=eps_u.shape[1])
+            self._unet_pass(latent, self._image_latents, self._image_embeddings, in_scale, step, euler=tail)
+            return out
         out = torch.empty_like(latent)
         ops.euler_step(latent, eps_c, eps_u, self._guidance32 if eps_u is not None else None, out,
                        ld_eps=eps_c.shape[1], sigma=sigma, sigma_next=sigma_next, b=b, frames=f, h=h, w=w)

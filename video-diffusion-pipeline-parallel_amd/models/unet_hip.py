@@ -412,10 +412,13 @@ class SVDUNetHIP:
         return self._gemm(r, p["pout"], mix, res1=x, r1scale=1.0)
 
     # ------------------------------------------------------------------ forward
-    def forward_rows(self, x_rows, *, b, frames, h, w, t_value, ctx16, added_ids32):
+    def forward_rows(self, x_rows, *, b, frames, h, w, t_value, ctx16, added_ids32, euler=None):
         """x_rows: fp16 [B*F*H*W][cin_pad] (see ``sp_pack_input_f16``); ``t_value``: fp32 device tensor [1]
         (continuous timestep); ``ctx16``: fp16 [B][cross_dim]; ``added_ids32``: fp32 device [3].
-        Returns eps rows fp16 [B*F*H*W][out_channels]."""
+        Returns eps rows fp16 [B*F*H*W][out_channels].  With ``euler`` (dict: latent, out, sigma, sigma_next and
+        optionally eps_uncond + guidance + ld_eps) the last convolution's epilogue applies the guidance mix and the
+        Euler update itself (ref svd_unet.py:410-439): ``euler["out"]`` receives the new latent, the
+        eps rows are not written and ``None`` is returned."""
         cfg, dev = self.cfg, self.device
         if h % 8 or w % 8:
             raise ValueError("latent height/width must be multiples of 8 (three stride-2 levels)")
@@ -480,6 +483,9 @@ class SVDUNetHIP:
                 r.h, r.w = ho, wo
         x = self._gn(r, self.norm_out, x, temporal=False, silu=True)
         geom, _, _ = self._conv_geom(r)
+        if euler is not None:
+            self._gemm(r, self.conv_out, x, conv=geom, euler=dict(euler, frames=r.f, hw=r.hw))
+            return None
         return self._gemm(r, self.conv_out, x, conv=geom)
 
     # diffusers-style call (sample (B,F,8,H,W)) – used by parity tests and as a drop-in `unet`
