@@ -95,15 +95,21 @@ typedef struct sp_gemm_desc {
   const float *euler_guidance;                         /* fp32 [frames] per-frame guidance scale (with euler_eps_uncond) */
   float euler_sigma, euler_sigma_next;
   int euler_frames; int64_t euler_hw;                  /* m = b*frames*hw + f*hw + pixel */
+  /* Optional scratch (the library never allocates): with at least sp_gemm_workspace_bytes(desc) bytes, contractions with
+     few rows and a long K (m <= 2560, K >= 8192: the 3x3 convolutions of the UNet's 2,016-row level) are split over K on 256 x 256 tiles,
+     fp32 partial sums go here and a second kernel reduces them and applies the epilogue.  NULL = never split. */
+  void *workspace; size_t workspace_bytes;
 } sp_gemm_desc;
 
 int sp_gemm_f16(const sp_gemm_desc *desc, void *stream);
+/* bytes of sp_gemm_desc.workspace this contraction can use (0: it is not a split-K candidate) */
+size_t sp_gemm_workspace_bytes(const sp_gemm_desc *desc);
 
 /* Test / micro-benchmark hook (no counterpart in the reference): pins the kernel family sp_gemm_f16 picks for the
  * shapes that family supports; everything else keeps the automatic choice.  Process-wide, not thread-safe: set it
  * before the calls it should affect.  route 0 = automatic (default), 1 = small tiles only, 2 = ping-pong large tiles
  * (bm in {0,128,192,256}, bn in {0,256,320}; 0 = automatic), 3 = persistent-stream tiles (bm in {0,192,256},
- * bn in {0,256}). */
+ * bn in {0,256}), 4 = split-K whenever a workspace is given (also for short K). */
 int sp_gemm_set_route(int route, int bm, int bn);
 
 /* y[n] = act_out( W[n][:] . act_in(x) + b[n] ), M = 1.  Replaces the nn.Linear GEMVs of the

@@ -35,7 +35,7 @@ def test_gemm_desc_layout_matches_header():
         if not stmt:
             continue
         parts = stmt.split(",")
-        first = re.sub(r"^(const\s+)?(void|float|int64_t|int)\s*\**\s*", "", parts[0].strip())
+        first = re.sub(r"^(const\s+)?(void|float|int64_t|size_t|int)\s*\**\s*", "", parts[0].strip())
         names.append(first.strip(" *"))
         names.extend(p.strip(" *") for p in parts[1:])
     assert names == [f[0] for f in hip.GemmDesc._fields_]

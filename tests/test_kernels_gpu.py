@@ -310,6 +310,82 @@ def test_gemm_with_folded_layernorm(m, c, n, geglu, route):
     check(out[1:m + 1], y, l2=3e-3, mx=2e-2)
 
 
+@pytest.mark.parametrize("case", ["conv3x3", "temporal_forced", "ff2_forced", "ln_geglu_forced", "ragged_forced"])
+def test_gemm_split_k(case):
+    """Split-K (sp_gemm_desc.workspace): the 2,016-row level's long-K contractions on 256 x 256 tiles, K slices summed
+    by the reduce kernel which also applies the epilogue.  The 3x3 convolution picks it automatically (K >= 8192); the
+    forced cases (route 4) cover shorter K, the folded LayerNorm + GEGLU epilogue and a ragged m / n_store.  The result has to
+    agree with fp32 torch and with the one-pass kernel on the same inputs (same rounding points: only the fp32
+    summation order differs), and no byte outside the promised workspace may be written."""
+    ops = _ops()
+    from vdpp_amd.models import weights as Wt
+    g = torch.Generator().manual_seed(len(case))
+    kw, route, geglu, n_store = {}, 0, False, 0
+    if case == "conv3x3":
+        nimg, hh, ww, cin, n = 14, 9, 16, 1280, 1280
+        x = h(torch.randn(nimg, cin, hh, ww, generator=g))
+        wc = h(torch.randn(n, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+        m = nimg * hh * ww
+        y = F.conv2d(x, wc, None, padding=1).permute(0, 2, 3, 1).reshape(m, n)
+        a, w = x.permute(0, 2, 3, 1).contiguous().half().to(DEV), Wt.pack_conv3x3(wc).to(DEV)
+        kw = dict(mode=ops.A_CONV3X3, conv=(nimg, hh, ww, hh, ww, 1, 0))
+    elif case == "temporal_forced":
+        route = 4
+        frames, hw, cin, n = 14, 144, 1280, 1280
+        m = frames * hw
+        x = h(torch.randn(1, cin, frames, hw, 1, generator=g))
+        w3 = h(torch.randn(n, cin, 3, 1, 1, generator=g) / math.sqrt(3 * cin))
+        y = F.conv3d(x, w3, None, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(m, n)
+        a, w = x[..., 0].permute(0, 2, 3, 1).reshape(m, cin).contiguous().half().to(DEV), Wt.pack_tconv3(w3).to(DEV)
+        kw = dict(mode=ops.A_TEMPORAL3, temporal=(frames, hw))
+    elif case == "ff2_forced":
+        route = 4
+        m, cin, n = 2016, 5120, 1280
+        xa = h(torch.randn(m, cin, generator=g)); wl = h(torch.randn(n, cin, generator=g) / math.sqrt(cin))
+        y = xa @ wl.t()
+        a, w = xa.half().to(DEV), wl.half().to(DEV)
+    else:
+        m, cin, n = (2016, 1280, 2560) if case == "ln_geglu_forced" else (1931, 320, 512)
+        route = 4
+        xa = h(torch.randn(m, cin, generator=g) + 2.0); wl = h(torch.randn(n, cin, generator=g) / math.sqrt(cin))
+        a = xa.half().to(DEV)
+        if case == "ln_geglu_forced":
+            from vdpp_amd.models.unet_hip import _Dense
+            gamma = 1.0 + 0.3 * torch.randn(cin, generator=g); beta = 0.5 * torch.randn(cin, generator=g)
+            bl = torch.randn(n, generator=g)
+            layer = _Dense.fold_layernorm(wl, bl, gamma, beta, DEV, eps=1e-5, geglu=True)
+            st = torch.empty(m, 2, device=DEV)
+            ops.ln_stats(a, st, rows=m, c=cin, eps=1e-5)
+            w, geglu = layer.w, True
+            kw = dict(ln_stats=st, ln_colsum=layer.colsum)
+            y = F.layer_norm(xa, (cin,), gamma, beta, eps=1e-5) @ wl.t() + bl
+            y = y[:, :n // 2] * F.gelu(y[:, n // 2:])
+            bias = layer.bias
+        else:
+            w, y, n_store = wl.half().to(DEV), xa @ wl.t(), 501
+            kw = dict(n_store=n_store, ldd=504)
+    nout = n // 2 if geglu else n
+    if case != "ln_geglu_forced":
+        bt = torch.randn(n, generator=g); bias = bt.to(DEV); y = y + bt
+        r1 = h(torch.randn(m, nout, generator=g)); y = y + 0.5 * r1
+        kw.update(res1=r1.half().to(DEV), r1scale=0.5, ldr1=nout)
+    need = ops.gemm_workspace_bytes(m=m, n=n, cin=cin, mode=kw.get("mode", ops.A_LINEAR))
+    assert need > 0
+    ws = torch.full((need // 4 + 256,), 55.0, device=DEV)
+    ns = n_store or nout
+    ldd = kw.pop("ldd", nout)
+    out = torch.full((m + 2, ldd), 7.0, dtype=torch.float16, device=DEV)
+    one = torch.full((m, ldd), 7.0, dtype=torch.float16, device=DEV)
+    with ops.gemm_route(route):
+        ops.gemm(a, w, out[1:m + 1], m=m, n=n, cin=cin, bias=bias, geglu=geglu, workspace=ws[:need // 4], ldd=ldd, **kw)
+        ops.gemm(a, w, one, m=m, n=n, cin=cin, bias=bias, geglu=geglu, ldd=ldd, **kw)       # one pass (no scratch)
+    torch.cuda.synchronize()
+    assert torch.all(ws[need // 4:] == 55.0) and not torch.all(ws[:need // 4] == 55.0), "split-K not taken / overran"
+    assert torch.all(out[0] == 7.0) and torch.all(out[m + 1] == 7.0) and torch.all(out[1:m + 1, ns:] == 7.0)
+    check(out[1:m + 1, :ns], y[:, :ns], l2=3e-3, mx=2e-2)
+    assert rel_l2(out[1:m + 1, :ns].float().cpu(), one[:, :ns].float().cpu()) < 6e-4
+
+
 @pytest.mark.parametrize("rows,c", [(100, 64), (1000, 320), (513, 640), (130, 1280)])
 def test_layernorm(rows, c):
     ops = _ops()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised cross-check of sp_gemm_f16 against fp32 torch (CPU): shapes, modes and epilogue flags drawn at random,
 output rows guarded on both sides (any write outside [0, m) x [0, n_store) fails).
-usage: fuzz_gemm.py [cases] [seed] [route] [bm]   (route / bm: sp_gemm_set_route, as in tests/test_fuzz_gpu.py)"""
+usage: fuzz_gemm.py [cases] [seed] [route] [bm]   (route / bm: sp_gemm_set_route, as in tests/test_fuzz_gpu.py;
+route 4 = split-K: few-row shapes with N % 256 == 0 drawn more often and a workspace handed to every call)"""
 import math, os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,16 +24,20 @@ def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-def one(rng, g, stream_shapes=False):
+def one(rng, g, stream_shapes=False, splitk=False):
     mode = rng.choice([0, 0, 1, 2])
     n = rng.choice([64, 128, 192, 256, 320, 512, 640, 960, 1280])
     cin = rng.choice([64, 128, 192, 320])
+    if splitk and rng.random() < 0.8:
+        n, cin = rng.choice([256, 512, 1280]), rng.choice([128, 320, 640])
     if stream_shapes and rng.random() < 0.7:          # what gemm_ps.hip takes: linear, K >= 256, N % 256 or % 320
         mode, n, cin = 0, rng.choice([256, 320, 512, 640, 960, 1280, 2560]), rng.choice([320, 640, 1280])
     geglu = mode == 0 and n % 128 == 0 and rng.random() < 0.3
     kw = {}
     if mode == 0:
         m = rng.choice([1, 7, 64, 255, 256, 257, 1000, 2560, 2561, 2700, 3000, 4097, 6001])
+        if splitk:
+            m = rng.choice([1, 7, 255, 256, 257, 1000, 2016, 2560])
         if stream_shapes and rng.random() < 0.5:
             m = rng.choice([12000, 20001, 33000, 48000])     # several tiles per workgroup of a 256-workgroup grid
         a = h(torch.randn(m, cin, generator=g))
@@ -41,6 +46,8 @@ def one(rng, g, stream_shapes=False):
         a_dev, w_dev = a.half().to(DEV), wt.half().to(DEV)
     elif mode == 1:
         nimg, hh, ww = rng.choice([1, 2, 5]), rng.choice([3, 8, 17, 24]), rng.choice([4, 9, 16, 40])
+        if splitk:
+            nimg, hh, ww = rng.choice([1, 2, 5]), rng.choice([3, 8, 9]), rng.choice([4, 9, 16])
         stride, ups = rng.choice([(1, 0), (1, 0), (2, 0), (1, 1)])
         x = h(torch.randn(nimg, cin, hh, ww, generator=g))
         wc = h(torch.randn(n, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
@@ -100,11 +107,17 @@ def one(rng, g, stream_shapes=False):
         kw.update(n_store=n_store)
         if "res1" in kw: kw["ldr1"] = nout
         if "res2" in kw: kw["ldr2"] = nout
+    if splitk:                         # scratch with a guard behind it (slabs must stay inside the promised bytes)
+        need = ops.gemm_workspace_bytes(m=m, n=n, cin=cin, mode=mode)
+        wsbuf = torch.full((need // 4 + 64,), 123.0, dtype=torch.float32, device=DEV)
+        kw.update(workspace=wsbuf[:need // 4] if need else None)
     buf = torch.full((m + 2 * GUARD, ldd), 7.0, dtype=torch.float16, device=DEV)
     out = buf[GUARD:GUARD + m]
     ops.gemm(a_dev, w_dev, out, m=m, n=n, cin=cin, bias=bias_dev, geglu=geglu, oscale=oscale, ldd=ldd, **kw)
     torch.cuda.synchronize()
     got = buf.float().cpu()
+    if splitk:
+        assert torch.all(wsbuf[need // 4:] == 123.0), "split-K slabs overran the workspace"
     desc = f"mode={mode} m={m} n={n} cin={cin} geglu={geglu} n_store={n_store} ldd={ldd} flags={sorted(k for k in kw if k not in ('mode', 'conv', 'temporal'))}"
     assert torch.all(got[:GUARD] == 7.0) and torch.all(got[GUARD + m:] == 7.0), "guard rows written: " + desc
     assert torch.all(got[GUARD:GUARD + m, n_store:] == 7.0), "columns past n_store written: " + desc
@@ -123,7 +136,7 @@ def main():
     worst = 0.0
     with ops.gemm_route(route, bm=bm):
         for i in range(cases):
-            worst = max(worst, one(rng, g, stream_shapes=route == 3))
+            worst = max(worst, one(rng, g, stream_shapes=route == 3, splitk=route == 4))
             if (i + 1) % 25 == 0:
                 print(f"{i + 1} cases ok, worst rel_l2 {worst:.2e}", flush=True)
     print(f"fuzz_gemm: {cases} cases passed (seed {seed}, route {route}, bm {bm}), worst rel_l2 {worst:.2e}")

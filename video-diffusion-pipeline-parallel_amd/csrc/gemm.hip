@@ -406,6 +406,76 @@ int launch(GemmArgs &a, hipStream_t s) {
 
 namespace {
 
+// Second half of a split-K contraction: sums the fp32 slabs of the K slices in slice order (deterministic) and applies
+// the whole sp_gemm_f16 epilogue (bias, bias2 row, folded LayerNorm, output scale, GEGLU, residuals, n_store).  One
+// thread per 8 output columns of one row.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, int nout, int nstore) {
+  const int cpr = (nstore + 7) >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)p.m * cpr) return;
+  const int64_t m = idx / cpr;
+  const int col = (int)(idx - m * cpr) * 8;
+  const int64_t slab = (int64_t)p.m * p.n;
+  // accumulator columns behind output columns col..col+7: the same columns, or for GEGLU the value / gate rows of the
+  // interleaved weight (blocks of 16: value 32q + r, gate 32q + 16 + r for output column 16q + r)
+  const int nv = p.geglu ? 32 * (col >> 4) + (col & 15) : col;
+  float v[8], g[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = g[e] = 0.f;
+  for (int sl = 0; sl < p.ksplit; ++sl) {
+    const float *src = p.partial + sl * slab + m * p.n + nv;
+    const f32x4 a0 = *(const f32x4 *)src, a1 = *(const f32x4 *)(src + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] += a0[e]; v[e + 4] += a1[e]; }
+    if (p.geglu) {
+      const f32x4 b0 = *(const f32x4 *)(src + 16), b1 = *(const f32x4 *)(src + 20);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { g[e] += b0[e]; g[e + 4] += b1[e]; }
+    }
+  }
+  float mean = 0.f, rstd = 1.f;
+  if (p.ln_stats) { mean = p.ln_stats[m * 2]; rstd = p.ln_stats[m * 2 + 1]; }
+  const int64_t brow = p.bias2 ? m / p.bias2_rows : 0;
+  auto finish = [&](float acc, int n) {
+    float b = p.bias ? p.bias[n] : 0.f;
+    if (p.bias2) b += p.bias2[brow * p.ldb2 + n];
+    return p.ln_stats ? (acc - mean * p.ln_colsum[n]) * rstd + b : acc + b;
+  };
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float f;
+    if (p.geglu) f = p.oscale * finish(v[e], nv + e) * gelu_f(finish(g[e], nv + 16 + e));
+    else f = p.oscale * finish(v[e], nv + e);
+    if (col + e < nstore) {
+      if (p.res1) f += p.r1scale * (float)p.res1[m * p.ldr1 + col + e];
+      if (p.res2) f += p.r2scale * (float)p.res2[m * p.ldr2 + col + e];
+    }
+    o[e] = (f16)f;
+  }
+  if (col + 8 <= nstore) {
+    *(f16x8 *)(p.d + m * p.ldd + col) = o;
+  } else {
+    for (int e = 0; e < nstore - col; ++e) p.d[m * p.ldd + col + e] = o[e];
+  }
+}
+
+// split-K plan for few-row contractions: number of K slices (0 = do not split) for 256 x 256 tiles
+int splitk_slices(const sp_gemm_desc *d, int taps, bool forced) {
+  if (d->n % 256 || d->m > 2560 || d->euler_out) return 0;
+  const int nk = taps * d->cin / 32;
+  // K >= 8192 (the 3x3 convolutions over 1280 / 2560 channels: 100 -> 74 us, 203 -> 120 us).  Slab writes + the reduce
+  // kernel cost ~20 us per call, which at K = 3840 / 5120 / 5760 (temporal convolution, FF2, 640-channel 3x3) is what
+  // the larger tiles save: measured 45 vs 38, 54 vs 50, 52 vs 51 us against 64 x 64 tiles.
+  if (!forced && nk < 256) return 0;
+  const int tiles = ((d->m + 255) / 256) * (d->n / 256);
+  int s = 256 / tiles;                                      // fill the 256 CUs once
+  const int min_steps = forced ? 4 : 16;
+  if (s > nk / min_steps) s = nk / min_steps;
+  if (s > 8) s = 8;
+  return s >= 2 ? s : 0;
+}
+
 // Kernel-family override for tests and micro-benchmarks (sp_gemm_set_route); 0 = automatic everywhere.
 int g_route = 0, g_route_bm = 0, g_route_bn = 0;
 
@@ -443,6 +513,22 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
     }
   }
 
+  // ---- few rows, long K (the 2016-row level's 3x3 convolutions): split-K on 256 x 256 tiles when
+  // the caller provides the fp32 workspace; 64 x 64 tiles move four times the operand bytes per FLOP
+  if ((route == 0 || route == 4) && d->workspace) {
+    const int sk = splitk_slices(d, a.taps, route == 4);
+    if (sk && d->workspace_bytes >= (size_t)sk * d->m * d->n * sizeof(float)) {
+      a.ksplit = sk;
+      a.partial = (float *)d->workspace;
+      if (int rc = launch_pp(a, 256, 256, s)) return rc;
+      const int nout = d->geglu ? d->n / 2 : d->n, nstore = d->n_store > 0 ? d->n_store : nout;
+      const int64_t work = (int64_t)d->m * ((nstore + 7) / 8);
+      SP_CLEAR_STALE_ERROR();
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a, nout, nstore);
+      SP_CHECK_LAUNCH("sp_gemm_f16(split-K reduce)");
+      return SP_OK;
+    }
+  }
   if (d->m <= 2560 && route != 2) {   // few rows (the 2016-row level): small tiles so the grid still covers 256 CUs
     if (d->n >= 3840 && n128) return launch<128, 128, 2, 2, 2>(a, s);
     return launch<64, 64, 2, 2, 3>(a, s);
@@ -477,8 +563,18 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
 
 }  // namespace
 
+extern "C" size_t sp_gemm_workspace_bytes(const sp_gemm_desc *d) {
+  if (!d || d->m <= 0 || d->n <= 0 || d->cin <= 0) return 0;
+  const int taps = d->mode == SP_A_CONV3X3 ? 9 : d->mode == SP_A_TEMPORAL3 ? 3 : 1;
+  int sk = splitk_slices(d, taps, false);
+  const int forced = splitk_slices(d, taps, true);
+  if (forced > sk) sk = forced;                             // (enough for a forced split in tests as well)
+  return (size_t)sk * d->m * d->n * sizeof(float);
+}
+
 extern "C" int sp_gemm_set_route(int route, int bm, int bn) {
-  SP_REQUIRE(route >= 0 && route <= 3, "sp_gemm_set_route: route %d (0 auto, 1 small tiles, 2 ping-pong, 3 persistent-stream)", route);
+  SP_REQUIRE(route >= 0 && route <= 4,
+             "sp_gemm_set_route: route %d (0 auto, 1 small tiles, 2 ping-pong, 3 persistent-stream, 4 split-K)", route);
   SP_REQUIRE(bm == 0 || bm == 128 || bm == 192 || bm == 256, "sp_gemm_set_route: bm %d", bm);
   SP_REQUIRE(bn == 0 || bn == 256 || bn == 320, "sp_gemm_set_route: bn %d", bn);
   g_route = route; g_route_bm = bm; g_route_bn = bn;

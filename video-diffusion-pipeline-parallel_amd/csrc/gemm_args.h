@@ -35,6 +35,8 @@ struct GemmArgs {
   float oscale, r1scale, r2scale;
   int geglu, n_store;
   int tiles_m, tiles_n;
+  int ksplit;          // > 1: K is cut into ksplit slices, fp32 partial sums go to `partial` ([ksplit][m][n])
+  float *partial;
   int dbg;   // ablation builds only (-DSP_GEMM_EXPERIMENTS + SP_GEMM_DBG): selects gemm_pp_kernel<.., EXP>
   int stagger;   // ablation builds only (SP_GEMM_STAGGER): first-round workgroups start (b/8 & 3) * stagger us late
 };

@@ -241,6 +241,7 @@ __device__ __forceinline__ void mfma_block(f32x4 (&acc)[TN][TM], const f16x8 (&f
 template <int BM, int BN, int EXP>
 __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const GemmArgs p) {
   constexpr int PBM = BM;
+  constexpr bool SPLITK = (EXP & 128) != 0;       // K-slice variant (only 256 x 256 is instantiated), see below
   constexpr int NWV = BM == 128 ? 4 : 8, NT = NWV * 64, WROWS = NWV / 4;   // waves, threads, wave rows (x 4 columns)
   constexpr int PSTAGES = pp_stages(BM, BN), PDIST = PSTAGES - 1;
   constexpr int TN = BN / 4 / 16;                 // weight sub-tiles per wave (4 or 5)
@@ -283,7 +284,11 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
 
   constexpr int GM = BM == 128 ? 8 : 4;
   const int nwg = p.tiles_m * p.tiles_n;
-  const int t = xcd_remap(blockIdx.x, nwg);
+  // split-K (few-row contractions with a long K, SPLITK instances): workgroup = (tile, K slice); slice s sums K-steps
+  // [s*nk/S, (s+1)*nk/S) into an fp32 slab of the workspace, splitk_reduce_kernel (gemm.hip) applies the epilogue
+  int bid = blockIdx.x, kslice = 0;
+  if constexpr (SPLITK) { kslice = bid / nwg; bid -= kslice * nwg; }
+  const int t = xcd_remap(bid, nwg);
   const int per_group = GM * p.tiles_n;
   const int group = t / per_group;
   const int first_m = group * GM;
@@ -397,11 +402,16 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
   for (int i = 0; i < TN; ++i) {
     bias_v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // (a folded LayerNorm applies its bias in the epilogue, after the row scaling)
-    if (p.bias && !p.ln_stats) bias_v[i] = *(const f32x4 *)(p.bias + tile_n * BN + wn * WTN + i * 16 + 4 * (lane >> 4));
+    if (p.bias && !p.ln_stats && !SPLITK)
+      bias_v[i] = *(const f32x4 *)(p.bias + tile_n * BN + wn * WTN + i * 16 + 4 * (lane >> 4));
   }
   __builtin_amdgcn_sched_barrier(0);
 
-  const int nk = p.k >> 5;
+  int nk = p.k >> 5, kbeg = 0;
+  if constexpr (SPLITK) {
+    kbeg = (int)((int64_t)kslice * nk / p.ksplit);
+    nk = (int)((int64_t)(kslice + 1) * nk / p.ksplit) - kbeg;
+  }
   const int fr = lane & 15, fq = lane >> 4;
   const int rd_chunk = (fq ^ swz4(fr)) << 4;      // fragment rows are (multiple of 16) + fr
   int offw[TN], offa[TM];
@@ -417,14 +427,22 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
     stage_slot = stage_slot + 1 == PSTAGES ? 0 : stage_slot + 1;
     ++staged; ++in_tap;
   };
-  set_tap(0);
+  tap = kbeg / cpt;
+  in_tap = kbeg - tap * cpt;
+  set_tap(tap);
+  if (kbeg) {                                   // a K slice starts in the middle of the weight rows (and of a tap)
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) aptr[i] += in_tap * astep[i];
+#pragma unroll
+    for (int j = 0; j < B_LOADS_LO; ++j) bptr[j] += (int64_t)kbeg * PBK;
+  }
   PP_TRACE(10);
 #pragma unroll
   for (int s = 0; s < PDIST; ++s)
     if (s < nk) stage_next();
   PP_TRACE(11);
   __builtin_amdgcn_sched_barrier(0);
-  if (p.bias2) {
+  if (p.bias2 && !SPLITK) {
     int brow[TM];
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -550,7 +568,18 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
   PP_TRACE_CLK(9);
   PP_TRACE(2);
 
-  if (p.geglu) {
+  if constexpr (SPLITK) {                         // raw fp32 sums of this K slice; the epilogue runs in the reduce kernel
+    float *slab = p.partial + (int64_t)kslice * p.m * p.n;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int64_t m = (int64_t)tile_m * PBM + wm * WTM + j * 16 + fr;
+      if (m < p.m) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          *(f32x4 *)(slab + m * p.n + tile_n * BN + wn * WTN + i * 16 + 4 * fq) = acc[i][j];
+      }
+    }
+  } else if (p.geglu) {
     if constexpr (TN % 2 == 0) pp_epilogue<PBM, BN, TN, TM, WTN, WTM, true, NT>(p, acc, smem, tile_m, tile_n, wm, wn, tid, fr, fq);
   } else {
     pp_epilogue<PBM, BN, TN, TM, WTN, WTM, false, NT>(p, acc, smem, tile_m, tile_n, wm, wn, tid, fr, fq);
@@ -570,7 +599,8 @@ int launch_pp(GemmArgs &a, hipStream_t s) {
   a.tiles_m = (a.m + BM - 1) / BM;
   a.tiles_n = a.n / BN;
   SP_CLEAR_STALE_ERROR();
-  hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, EXP>), dim3(a.tiles_m * a.tiles_n), dim3(BM == 128 ? 256 : 512), lds, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, EXP>), dim3(a.tiles_m * a.tiles_n * ((EXP & 128) ? a.ksplit : 1)),
+                     dim3(BM == 128 ? 256 : 512), lds, s, a);
   SP_CHECK_LAUNCH("sp_gemm_f16(pp)");
   return SP_OK;
 }
@@ -578,6 +608,7 @@ int launch_pp(GemmArgs &a, hipStream_t s) {
 }  // namespace
 
 int launch_pp(GemmArgs &a, int bm, int bn, hipStream_t s) {
+  if (a.ksplit > 1) return launch_pp<256, 256, 128>(a, s);
 #ifdef SP_GEMM_EXPERIMENTS
   if (bm == 256 && bn == 256) switch (a.dbg) {
     case 1: return launch_pp<256, 256, 1>(a, s);

@@ -35,6 +35,7 @@ class GemmDesc(ctypes.Structure):
         ("euler_guidance", ctypes.c_void_p),
         ("euler_sigma", ctypes.c_float), ("euler_sigma_next", ctypes.c_float),
         ("euler_frames", ctypes.c_int), ("euler_hw", ctypes.c_int64),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
     ]
 
 
@@ -44,6 +45,7 @@ SIGNATURES = {
     "sp_last_error": (ctypes.c_char_p, []),
     "sp_version": (_I, []),
     "sp_gemm_f16": (_I, [ctypes.POINTER(GemmDesc), _P]),
+    "sp_gemm_workspace_bytes": (_Z, [ctypes.POINTER(GemmDesc)]),
     "sp_gemm_set_route": (_I, [_I, _I, _I]),
     "sp_gemv_f16": (_I, [_P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "sp_gemv_batched_f16": (_I, [_P, _L, _L, _P, _L, _P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P]),

@@ -81,7 +81,8 @@ def _rows(t: torch.Tensor, name: str, ld: int) -> torch.Tensor:
 
 def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=None, bias=None,
          bias2=None, bias2_rows=0, ldb2=0, res1=None, r1scale=1.0, res2=None, r2scale=1.0, oscale=1.0,
-         geglu=False, n_store=0, ldd=None, ldr1=None, ldr2=None, ln_stats=None, ln_colsum=None, euler=None):
+         geglu=False, n_store=0, ldd=None, ldr1=None, ldr2=None, ln_stats=None, ln_colsum=None, euler=None,
+         workspace=None):
     """``out[m][:] = epilogue(sum_taps A_tap @ W^T)``; see ``sp_gemm_desc`` in include/svdpipe.h.
     ``ln_stats`` / ``ln_colsum``: LayerNorm folded into the contraction (``a`` is the UN-normalised tensor)."""
     d = GemmDesc()
@@ -107,6 +108,8 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
         d.euler_ld_eps = int(euler.get("ld_eps", 0))
         d.euler_sigma, d.euler_sigma_next = float(euler["sigma"]), float(euler["sigma_next"])
         d.euler_frames, d.euler_hw = int(euler["frames"]), int(euler["hw"])
+    if workspace is not None:      # fp32 scratch for split-K (few rows, long K); too small a buffer simply disables it
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     taps = 9 if mode == A_CONV3X3 else 3 if mode == A_TEMPORAL3 else 1
     # algorithmic bytes of this launch: every operand element once (A without tap re-reads), output and residuals once
     a_rows = d.n_img * d.hin * d.win if mode == A_CONV3X3 else m
@@ -114,6 +117,13 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
     with _Timed("gemm", 2.0 * m * n * taps * cin, nbytes):
         _check(load().sp_gemm_f16(ctypes.byref(d), _stream()), "sp_gemm_f16")
     return out
+
+
+def gemm_workspace_bytes(*, m, n, cin, mode=A_LINEAR) -> int:
+    """Scratch bytes ``gemm(..., workspace=)`` can use for this shape (0: not a split-K candidate)."""
+    d = GemmDesc()
+    d.m, d.n, d.cin, d.mode = m, n, cin, mode
+    return int(load().sp_gemm_workspace_bytes(ctypes.byref(d)))
 
 
 class gemm_route:

@@ -107,6 +107,7 @@ class _Run:
     temb: torch.Tensor          # fp32 [n_temb_total] : every time_emb_proj(silu(emb)) of the net
     ctx16: torch.Tensor         # fp16 [B][cross_dim]
     gn_ws: torch.Tensor
+    sk_ws: torch.Tensor         # fp32 scratch for split-K contractions of the few-row levels (None: no such level)
     frame_ids: torch.Tensor     # fp32 [F] = arange(F)
     cross: dict = None          # width C -> fp32 [modules][B][C]: to_out(to_v(ctx)) + b of every cross-attention of that width
     pos: dict = None            # width C -> fp16 [transformers][F][C]: frame position embeddings
@@ -185,6 +186,7 @@ class SVDUNetHIP:
         del self._temb_w, self._temb_b
         self._group_small_gemvs()
         self._gn_ws = None
+        self._sk_ws = {}
         self._fp8_ws = {}
 
     # ------------------------------------------------------------------ weight packing
@@ -313,7 +315,7 @@ class SVDUNetHIP:
             raise RuntimeError("this contraction carries a folded LayerNorm: pass ln_stats")
         ops.gemm(a, layer.w, out, m=m, n=layer.n, cin=layer.cin, mode=layer.mode, conv=conv, temporal=temporal,
                  bias=layer.bias, geglu=layer.geglu, n_store=n_store, ldd=layer.n_true, lda=a.shape[1],
-                 ln_colsum=layer.colsum, **kw)
+                 ln_colsum=layer.colsum, workspace=r.sk_ws if m <= 2560 else None, **kw)
         return out
 
     def _ln_stats(self, layer: _Dense, x, **kw):
@@ -433,6 +435,16 @@ class SVDUNetHIP:
         if gn_ws is None or gn_ws.numel() < ws_bytes:
             gn_ws = self._gn_ws[skey] = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
 
+        # split-K scratch for the levels with at most 2,560 rows (up to 8 fp32 slabs of rows x channels), per stream as well
+        sk_bytes = 0
+        for lvl, c in enumerate(cfg.block_out_channels):
+            rows = b * frames * (h >> min(lvl, 3)) * (w >> min(lvl, 3))
+            if rows <= 2560:
+                sk_bytes = max(sk_bytes, 8 * rows * c * 4)
+        sk_ws = self._sk_ws.get(skey)
+        if sk_bytes and (sk_ws is None or sk_ws.numel() < sk_bytes):
+            sk_ws = self._sk_ws[skey] = torch.empty(sk_bytes, dtype=torch.uint8, device=dev)
+
         # ---- embeddings (M = 1 GEMVs)
         hid = torch.empty((1, 2 * temb_dim), dtype=torch.float16, device=dev)
         tsin = torch.empty((1, c0), dtype=torch.float16, device=dev)
@@ -447,7 +459,7 @@ class SVDUNetHIP:
         temb = torch.empty(self.temb_w.shape[0], dtype=torch.float32, device=dev)
         ops.gemv(emb16, self.temb_w, self.temb_b, n=self.temb_w.shape[0], k=temb_dim, y32=temb, silu_in=True)
 
-        r = _Run(b=b, f=frames, h=h, w=w, temb=temb, ctx16=ctx16, gn_ws=gn_ws,
+        r = _Run(b=b, f=frames, h=h, w=w, temb=temb, ctx16=ctx16, gn_ws=gn_ws, sk_ws=sk_ws,
                  frame_ids=torch.arange(frames, dtype=torch.float32, device=dev))
         self._small_gemvs(r)
 
