@@ -386,6 +386,31 @@ def test_gemm_split_k(case):
     assert rel_l2(out[1:m + 1, :ns].float().cpu(), one[:, :ns].float().cpu()) < 6e-4
 
 
+@pytest.mark.parametrize("rows,c", [(100, 64), (4099, 320), (12345, 320), (5001, 640), (4097, 960), (6002, 1280), (130, 1280)])
+def test_ln_stats_rows_per_wave(rows, c):
+    """sp_ln_stats_f16: several rows per wave (ragged row counts: the last wave's clamped rows must not be written),
+    with and without the per-frame pre-add and the written-out sum; vs fp64 row statistics of the fp16 values."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows + c)
+    x = h(torch.randn(rows, c, generator=g) * 2 + 5 * torch.randn(rows, 1, generator=g))
+    st = torch.full((rows + 1, 2), -7.0, device=DEV)
+    ops.ln_stats(x.half().to(DEV), st[:rows], rows=rows, c=c, eps=1e-5)
+    xd = x.double()
+    assert torch.all(st[rows] == -7.0)
+    assert float((st[:rows, 0].cpu().double() - xd.mean(1)).abs().max()) < 1e-4
+    assert rel_l2(st[:rows, 1].cpu(), (xd.var(1, unbiased=False) + 1e-5).rsqrt().float()) < 1e-5
+    per = 50
+    add = h(torch.randn((rows + per - 1) // per, c, generator=g))
+    sm = torch.full((rows + 1, c), 7.0, dtype=torch.float16, device=DEV)
+    ops.ln_stats(x.half().to(DEV), st[:rows], rows=rows, c=c, eps=1e-5, addvec=add.half().to(DEV), addvec_rows=per,
+                 sum_out=sm[:rows])
+    xs = (x + add.repeat_interleave(per, 0)[:rows]).half()
+    assert torch.equal(sm[:rows].cpu(), xs) and torch.all(sm[rows] == 7.0) and torch.all(st[rows] == -7.0)
+    xsd = xs.double()
+    assert float((st[:rows, 0].cpu().double() - xsd.mean(1)).abs().max()) < 1e-4
+    assert rel_l2(st[:rows, 1].cpu(), (xsd.var(1, unbiased=False) + 1e-5).rsqrt().float()) < 1e-5
+
+
 @pytest.mark.parametrize("rows,c", [(100, 64), (1000, 320), (513, 640), (130, 1280)])
 def test_layernorm(rows, c):
     ops = _ops()

@@ -1,77 +1,163 @@
-// Probe: LDS-DMA (global_load_lds_dwordx4) throughput per CU for two source shapes at equal bytes:
-//   mode 0: 1 KiB piece = 8 rows x 128 B (full cache lines)      mode 1: 1 KiB piece = 16 rows x 64 B (half lines)
-// Each workgroup (512 threads) streams `rows` rows of a [R][K] fp16 matrix like a GEMM A/B tile would.
+// Probe: how fast can one 512-thread workgroup per CU pull operand slabs through the vector memory path, by the SHAPE of
+// the access (the question behind the GEMM K-step: is 43 GB/s per CU a limit of the path or of the 64-byte rows?)
+//   shape 0: 16 rows x  64 B per wave instruction (what a BK = 32 fp16 K-step reads: half a 128-byte line per row)
+//   shape 1:  8 rows x 128 B per wave instruction (full lines: a BK = 64 K-step)
+//   shape 2:  4 rows x 256 B
+//   shape 3:  1 KiB contiguous
+//   shape 4: as shape 0, but every wave issues the two halves of a line back to back (the pieces of K-steps 2i and
+//            2i+1 interleaved, two K-steps staged at a time): does the second half then hit in the CU's L1?
+// x path 0 = global_load_lds_dwordx4 (LDS-DMA, 4-stage ring of 32 KiB), 1 = global_load_dwordx4 into registers
+// x source 0 = L2-resident (every XCD's workgroups walk the same 2 MiB), 1 = HBM stream (fresh bytes per workgroup)
+// x grid 256 (every CU) / 32 / 8 / 1 workgroups.
+// Row stride 2560 B (K = 1280 fp16).  Every step a workgroup reads 32 KiB = 32 instructions of 1 KiB; consecutive
+// steps advance along the row by the row width (the K direction), wrapping to the next row block after the row ends --
+// so with 64-byte rows the second half of every line is asked for one step later, as in the GEMM.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include <vector>
-__device__ __forceinline__ void glds16(const void *g, void *l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                   (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                   (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
 }
-template <int MODE>
-__global__ __launch_bounds__(512) void probe(const char *base, long row_bytes, int rows_total, int ksteps, int share) {
+
+template <int SHAPE, int PATH>
+__global__ __launch_bounds__(512) void probe(const char *src, int hbm, int steps, float *sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // block b reads the row panel (b / share): `share` blocks read the same panel (L2 reuse like GEMM tiles)
-  const int panel = blockIdx.x / share;
-  const long row0 = ((long)panel * 512) % rows_total;
-  for (int ks = 0; ks < ksteps; ++ks) {
-    char *slot = smem + (ks & 3) * 32768;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const char *src;
-      if (MODE == 0) {  // 8 rows x 128 B; this K-step covers 64 B per row for 512 rows -> here 256 rows x 128 B
-        const int r = (i * 8 + wave) * 8 + (lane >> 3);
-        src = base + (row0 + r) * row_bytes + (long)ks * 128 + (lane & 7) * 16;
-      } else if (MODE == 1) {          // 16 rows x 64 B, 512 rows x 64 B per K-step
-        const int r = (i * 8 + wave) * 16 + (lane >> 2);
-        src = base + (row0 + r) * row_bytes + (long)ks * 64 + (lane & 3) * 16;
-      } else {          // MODE 2: like mode 1 but two consecutive K-steps (same lines) issued back to back
-        const int r = (i * 8 + wave) * 16 + (lane >> 2);
-        src = base + (row0 + r) * row_bytes + (long)(ks * 2) * 64 + (lane & 3) * 16;
-        glds16(src, slot + (i * 8 + wave) * 1024);
-        src += 0;  // first half issued; the second half of the same lines follows in the second loop below
-      }
-      if (MODE != 2) glds16(src, slot + (i * 8 + wave) * 1024);
+  constexpr int ROWB = (SHAPE == 0 || SHAPE == 4) ? 64 : SHAPE == 1 ? 128 : SHAPE == 2 ? 256 : 1024;   // bytes per row per instruction
+  constexpr int RPI = 1024 / ROWB;                                                     // rows per instruction
+  constexpr long LD = 2560;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane / (ROWB / 16), lchunk = lane % (ROWB / 16);
+  // 32 instructions per step = 32 * RPI rows of ROWB bytes; a row block = 32 * RPI rows x LD bytes
+  const long rows_per_step = 32 * RPI;
+  const int steps_per_row = SHAPE == 3 ? 1 : (int)(LD / ROWB);
+  // L2-resident: the workgroups of an XCD (blockIdx % 8) walk the same 2 MiB window, 64 KiB apart; HBM: 8 MiB each
+  const char *base = hbm ? src + (long)blockIdx.x * (8L << 20) : src + (long)(blockIdx.x & 7) * (2L << 20);
+  const long start = hbm ? 0 : (long)(blockIdx.x >> 3) * 65536;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  auto addr = [&](int step, int j) -> const char * {
+    long off;
+    if (SHAPE == 3) {
+      off = (long)step * 32768 + (long)(j * 8 + wave) * 1024 + lane * 16;
+    } else {
+      const int blk = step / steps_per_row, kk = step - blk * steps_per_row;
+      const long row = (long)blk * rows_per_step + (long)(j * 8 + wave) * RPI + lrow;
+      off = row * LD + (long)kk * ROWB + lchunk * 16;
     }
-    if (MODE == 2) {
-      char *slot2 = smem + ((ks + 2) & 3) * 32768;
+    off += start;
+    if (!hbm) off &= (2L << 20) - 1;
+    return base + off;
+  };
+  if (PATH == 0 && SHAPE == 4) {
+    // 4-stage ring, K-steps staged in pairs: (s, s+1) issued together, piece by piece
+    auto pair = [&](int s) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = (i * 8 + wave) * 16 + (lane >> 2);
-        glds16(base + (row0 + r) * row_bytes + (long)(ks * 2 + 1) * 64 + (lane & 3) * 16, slot2 + (i * 8 + wave) * 1024);
+      for (int j = 0; j < 4; ++j) {
+        glds16(addr(s, j), smem + (s & 3) * 32768 + (j * 8 + wave) * 1024);
+        glds16(addr(s + 1, j), smem + ((s + 1) & 3) * 32768 + (j * 8 + wave) * 1024);
       }
-    }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0 && smem[0] == 123) printf("x");
-}
-int main(int argc, char **argv) {
-  const int share = argc > 1 ? atoi(argv[1]) : 8;
-  const long K = 4096, row_bytes = K * 2;
-  const int rows_total = 65536;
-  char *d; hipMalloc(&d, rows_total * row_bytes); hipMemset(d, 1, rows_total * row_bytes);
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int mode = 0; mode < 3; ++mode) {
-    const int ksteps = mode == 1 ? 128 : 64;      // both walk 8 KB per row
-    const int blocks = 256 * 4;
-    auto launch = [&]() {
-      if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(512), 131072, 0, d, row_bytes, rows_total, ksteps, share);
-      else if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(512), 131072, 0, d, row_bytes, rows_total, ksteps, share);
-      else hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(512), 131072, 0, d, row_bytes, rows_total, ksteps, share);
     };
-    hipFuncSetAttribute((const void *)probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    hipFuncSetAttribute((const void *)probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    hipFuncSetAttribute((const void *)probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    launch(); hipDeviceSynchronize();
-    hipEventRecord(e0); for (int i = 0; i < 5; ++i) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
-    const double bytes = (double)blocks * ksteps * 32768.0 * (mode == 2 ? 2 : 1);
-    printf("mode %d (%s) share %d: %.1f us, %.2f TB/s aggregate, %.1f GB/s per CU\n", mode,
-           mode == 0 ? "8 rows x 128 B" : mode == 1 ? "16 rows x 64 B" : "16x64B, k and k+1 paired", share, ms * 1e3, bytes / ms / 1e9, bytes / ms / 1e6 / 256);
+    pair(0);
+    for (int s = 0; s < steps; s += 2) {
+      if (s + 2 < steps) {
+        pair(s + 2);
+        __builtin_amdgcn_s_waitcnt(0x0f70 | 8);         // vmcnt(8): steps s, s+1 have landed
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+      }
+      __builtin_amdgcn_s_barrier();
+      acc += *(const f32x4 *)(smem + (s & 3) * 32768 + tid * 16);
+      acc += *(const f32x4 *)(smem + ((s + 1) & 3) * 32768 + tid * 16);
+      __builtin_amdgcn_s_barrier();
+    }
+  } else if (PATH == 0) {
+    // 4-stage ring, 3 steps in flight
+    for (int s = 0; s < 3 && s < steps; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) glds16(addr(s, j), smem + (s & 3) * 32768 + (j * 8 + wave) * 1024);
+    for (int s = 0; s < steps; ++s) {
+      if (s + 3 < steps) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(addr(s + 3, j), smem + ((s + 3) & 3) * 32768 + (j * 8 + wave) * 1024);
+        __builtin_amdgcn_s_waitcnt(0x0f70 | 12);        // vmcnt(12): step s has landed
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0f70);             // vmcnt(0)
+      }
+      __builtin_amdgcn_s_barrier();
+      // touch the stage so the reads cannot be dropped (one ds_read per lane)
+      acc += *(const f32x4 *)(smem + (s & 3) * 32768 + tid * 16);
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    for (int s = 0; s < steps; s += 2) {
+      f32x4 v[8];
+      if (SHAPE == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = *(const f32x4 *)addr(s, j); v[2 * j + 1] = *(const f32x4 *)addr(s + 1, j); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *(const f32x4 *)addr(s, j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 + j] = *(const f32x4 *)addr(s + 1 < steps ? s + 1 : s, j);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += v[j];
+    }
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) sink[blockIdx.x] = acc[0];
+}
+
+template <int SHAPE, int PATH>
+float run(const char *src, int hbm, int steps, float *sink, int grid) {
+  hipFuncSetAttribute((const void *)probe<SHAPE, PATH>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((probe<SHAPE, PATH>), dim3(grid), dim3(512), 131072, 0, src, hbm, steps, sink);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int i = 0; i < 3; ++i)
+    hipLaunchKernelGGL((probe<SHAPE, PATH>), dim3(grid), dim3(512), 131072, 0, src, hbm, steps, sink);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return ms / 3;
+}
+
+int main() {
+  const long total = 3L << 30;                     // 3 GiB source
+  char *src; float *sink;
+  if (hipMalloc(&src, total) != hipSuccess) { printf("alloc failed\n"); return 1; }
+  hipMemset(src, 1, total);
+  hipMalloc(&sink, 4096);
+  const char *shapes[5] = {"16 rows x  64 B", " 8 rows x 128 B", " 4 rows x 256 B", "1 KiB contiguous", "16 x 64 B, halves paired"};
+  const int grids[2] = {256, 32};
+  for (int hbm = 0; hbm < 2; ++hbm) {
+    const int steps = hbm ? 240 : 2048;
+    for (int gi = 0; gi < 2; ++gi) {
+      const int grid = grids[gi];
+      for (int path = 0; path < 2; ++path)
+        for (int shape = 0; shape < 5; ++shape) {
+          float ms;
+          switch (shape * 2 + path) {
+            case 0: ms = run<0, 0>(src, hbm, steps, sink, grid); break;
+            case 1: ms = run<0, 1>(src, hbm, steps, sink, grid); break;
+            case 2: ms = run<1, 0>(src, hbm, steps, sink, grid); break;
+            case 3: ms = run<1, 1>(src, hbm, steps, sink, grid); break;
+            case 4: ms = run<2, 0>(src, hbm, steps, sink, grid); break;
+            case 5: ms = run<2, 1>(src, hbm, steps, sink, grid); break;
+            case 6: ms = run<3, 0>(src, hbm, steps, sink, grid); break;
+            case 7: ms = run<3, 1>(src, hbm, steps, sink, grid); break;
+            case 8: ms = run<4, 0>(src, hbm, steps, sink, grid); break;
+            default: ms = run<4, 1>(src, hbm, steps, sink, grid); break;
+          }
+          const double bytes = (double)grid * steps * 32768;
+          printf("%-12s grid %3d  %-10s %s : %8.1f us  %7.2f TB/s  %6.1f GB/s per CU\n", hbm ? "HBM stream" : "L2-resident",
+                 grid, path == 0 ? "LDS-DMA" : "registers", shapes[shape], ms * 1e3, bytes / ms / 1e9,
+                 bytes / ms / 1e6 / grid);
+          fflush(stdout);
+        }
+    }
   }
   return 0;
 }

@@ -37,13 +37,18 @@ def main():
         if kind == "gemm":
             key = ("gemm",) + shapes[gi]; gi += 1
         else:
-            key = (kind, fl)
-        a = agg.setdefault(key, [0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl
+            key = (kind, fl or _nb)
+        a = agg.setdefault(key, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl; a[3] += _nb
     rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
     tot = sum(v[1] for v in agg.values())
     print(f"total timed {tot:.2f} ms")
-    for k, (n, ms, fl) in rows[:60]:
-        print(f"{str(k):60s} x{n:3d} {ms:8.3f} ms  {ms/n*1000:9.1f} us/launch  {fl/ms/1e9:8.1f} TF/s")
+    for k, (n, ms, fl, nb) in rows[:80]:
+        print(f"{str(k):60s} x{n:3d} {ms:8.3f} ms  {ms/n*1000:9.1f} us/launch  {fl/ms/1e9:8.1f} TF/s  {nb/ms/1e9:7.2f} TB/s (algorithmic)")
+    kinds = collections.OrderedDict()
+    for k, (n, ms, fl, nb) in agg.items():
+        a = kinds.setdefault(k[0], [0, 0.0]); a[0] += n; a[1] += ms
+    for k, (n, ms) in sorted(kinds.items(), key=lambda kv: -kv[1][1]):
+        print(f"  {k:16s} {n:4d} launches {ms:8.3f} ms")
 
 if __name__ == "__main__":
     main()

@@ -56,23 +56,19 @@ __device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3)
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// at most `young` K-steps of this wave's DMA (L instructions each) plus `extra` other operations may stay outstanding
+// s_waitcnt vmcnt(n) for a wave-uniform n that is a compile-time constant at every (inlined) call site
+__device__ __forceinline__ void wait_count(int n) {
+#define W1(x) case x: wait_vm<x>(); break;
+#define W8(x) W1(x) W1(x + 1) W1(x + 2) W1(x + 3) W1(x + 4) W1(x + 5) W1(x + 6) W1(x + 7)
+  switch (n) { W8(0) W8(8) W8(16) W8(24) W8(32) W8(40) W8(48) W8(56) default: wait_vm<0>(); break; }
+#undef W8
+#undef W1
+}
+// at most `young` K-steps of this wave's DMA (L instructions each) plus `extra` other operations may stay outstanding;
+// extra_kind: 0 none, 1 = X1 (first tile: bias pieces), 2 = X2 (later tiles: stores + bias pieces)
 template <int L, int X1, int X2>
 __device__ __forceinline__ void wait_stream(int young, int extra_kind) {
-  // extra_kind: 0 none, 1 = X1 (first tile: bias pieces), 2 = X2 (later tiles: stores + bias pieces)
-  if (extra_kind == 0) {
-    if (young >= 2) wait_vm<2 * L>();
-    else if (young == 1) wait_vm<L>();
-    else wait_vm<0>();
-  } else if (extra_kind == 1) {
-    if (young >= 2) wait_vm<2 * L + X1>();
-    else if (young == 1) wait_vm<L + X1>();
-    else wait_vm<X1>();
-  } else {
-    if (young >= 2) wait_vm<2 * L + X2>();
-    else if (young == 1) wait_vm<L + X2>();
-    else wait_vm<X2>();
-  }
+  wait_count(young * L + (extra_kind == 0 ? 0 : extra_kind == 1 ? X1 : X2));
 }
 
 __device__ __forceinline__ unsigned pack_h2(float a, float b) {
@@ -90,9 +86,10 @@ __device__ __forceinline__ void swap16(unsigned &a, unsigned &b) {
   b = r[1];
 }
 
-template <int BM, int BN, int WM, int WN, bool GEGLU>
+template <int BM, int BN, int WM, int WN, bool GEGLU, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
   static_assert(WM * WN == 8, "eight waves");
+  constexpr bool PAIR = (VAR & 1) != 0;                    // K-steps staged in pairs (see stage2)
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
   constexpr int TNO = GEGLU ? TN / 2 : TN;                 // output sub-tiles (16 columns) per wave
   static_assert(TNO % 2 == 0, "output sub-tiles are written in pairs");
@@ -180,11 +177,39 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
     b_base += SBK * 2;
   };
 
+  // PAIR: two K-steps at a time, piece by piece -- a K-step reads 64 of the 128 bytes of every line it touches, and
+  // with the other half requested one K-step (32 KiB of other lines through a 32 KiB L1) later every line travels from
+  // L2 twice.  Back to back the second half hits in L1: tools/dma_probe.hip, all CUs on L2-resident rows, 63 -> 104 GB/s
+  // per CU.  The kernel is not bound there (+0-4 %), see DESIGN.md.  (nk is even: the host checks.)
+  auto stage2 = [&]() {
+    char *sa = smem + p_slot * STAGE;              // p_slot is 0 or 2
+    char *sb = sa + A_BYTES;
+    p_slot ^= 2;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i)
+      if (i < A_LOADS_HI || wave < A_SPLIT) {
+        glds16(a_base + a_off[i], sa + (i * 8 + wave) * 1024);
+        glds16(a_base + a_off[i] + SBK * 2, sa + STAGE + (i * 8 + wave) * 1024);
+      }
+#pragma unroll
+    for (int j = 0; j < B_LOADS; ++j)
+      if (j < B_LOADS_HI || wave < B_SPLIT) {
+        glds16(b_base + b_off[j], sb + (j * 8 + wave) * 1024);
+        glds16(b_base + b_off[j] + SBK * 2, sb + STAGE + (j * 8 + wave) * 1024);
+      }
+    a_base += SBK * 4;
+    b_base += SBK * 4;
+  };
+
   int c_tm, c_tn;                                  // consumer's tile
   decode((int)blockIdx.x, c_tm, c_tn);
   set_tile(c_tm, c_tn);
+  if constexpr (PAIR) {
+    stage2(); stage2();
+  } else {
 #pragma unroll
-  for (int s = 0; s < SSTAGES; ++s) stage();       // the whole ring: K-steps 0..3 (nk >= 8)
+    for (int s = 0; s < SSTAGES; ++s) stage();     // the whole ring: K-steps 0..3 (nk >= 8)
+  }
 
   const int rd_chunk = (fq ^ swz4(fr)) << 4;       // fragment rows are (multiple of 16) + fr
   int offw[TN], offa[TM];
@@ -198,7 +223,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
   const __amdgpu_buffer_rsrc_t d_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)p.d, 0, (int)min((int64_t)p.m * p.ldd * 2, (int64_t)0x7fffffff), 0x00020000);
 
-  if (late) wait_vm<3 * L_LATE>(); else wait_vm<3 * L_EARLY>();    // K-step 0 landed (this wave's part)
+  if constexpr (PAIR) {
+    if (late) wait_vm<2 * L_LATE>(); else wait_vm<2 * L_EARLY>();  // K-steps 0 and 1 landed (this wave's part)
+  } else {
+    if (late) wait_vm<3 * L_LATE>(); else wait_vm<3 * L_EARLY>();  // K-step 0 landed (this wave's part)
+  }
   __builtin_amdgcn_s_barrier();
 #ifdef SP_GEMM_EXPERIMENTS
   ps_first = ps_t = PS_NOW();
@@ -238,8 +267,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
       glds16(b2, bias_lds + 1024);
       glds16(b3, bias_lds + 2048);
     }
-    if (issue) stage();
-    if (late) wait_stream<L_LATE, NBIAS, NSTORE + NBIAS>(young, xk);
+    if (issue) { if constexpr (PAIR) stage2(); else stage(); }
+    if (late && young >= 0) wait_stream<L_LATE, NBIAS, NSTORE + NBIAS>(young, xk);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -252,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
-    if (!late) wait_stream<L_EARLY, NBIAS, NSTORE + NBIAS>(young, xk);
+    if (!late && young >= 0) wait_stream<L_EARLY, NBIAS, NSTORE + NBIAS>(young, xk);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -276,28 +305,46 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
     // K-steps 0 .. nk-4: the stream stays inside this tile.  K-steps 0..3 are already in the ring (K-step 3 was issued
     // ahead of the previous tile's stores), so K-step kt issues kt+3 from kt = 1 on; while K-step 3 is the youngest
     // load the previous tile's stores and this tile's bias pieces sit behind it in the queue (xk0).
-    kstep(false, 2, xk0, true);
-    kstep(true, 2, xk0, false);
-    kstep(true, 2, xk0, false);
-    for (int kt = 3; kt < nk - SDIST; ++kt) kstep(true, 2, 0, false);
-    // K-steps nk-3 .. nk-1: the stream moves on to the first three K-steps of this workgroup's next tile
     int n_tm = c_tm, n_tn = c_tn;
-    if (more) {
-      decode((int)blockIdx.x + (ti + 1) * (int)gridDim.x, n_tm, n_tn);
-      set_tile(n_tm, n_tn);
+    if constexpr (PAIR) {
+      // Pairs (0,1) and (2,3) are in the ring (issued ahead of the previous tile's stores).  Even K-step k issues the
+      // pair (k+2, k+3) into the slots of k-2 and k-1; odd K-step k waits for the whole pair (k+1, k+2) -- nothing
+      // younger is in the queue then, except behind the tile boundary: the previous tile's stores and the bias pieces.
+      kstep(false, -1, 0, true);
+      kstep(false, 0, xk0, false);
+      for (int kt = 2; kt < nk - 2; kt += 2) {
+        kstep(true, -1, 0, false);
+        kstep(false, 0, 0, false);
+      }
+      if (more) {
+        decode((int)blockIdx.x + (ti + 1) * (int)gridDim.x, n_tm, n_tn);
+        set_tile(n_tm, n_tn);
+      }
+      kstep(more, -1, 0, false);                   // the next tile's pair (0,1)
+      kstep(false, 0, 0, false);
+    } else {
+      kstep(false, 2, xk0, true);
+      kstep(true, 2, xk0, false);
+      kstep(true, 2, xk0, false);
+      for (int kt = 3; kt < nk - SDIST; ++kt) kstep(true, 2, 0, false);
+      // K-steps nk-3 .. nk-1: the stream moves on to the first three K-steps of this workgroup's next tile
+      if (more) {
+        decode((int)blockIdx.x + (ti + 1) * (int)gridDim.x, n_tm, n_tn);
+        set_tile(n_tm, n_tn);
+      }
+      kstep(more, more ? 2 : 1, 0, false);
+      kstep(more, more ? 2 : 0, 0, false);
+      kstep(more, more ? 2 : 0, 0, false);
     }
-    kstep(more, more ? 2 : 1, 0, false);
-    kstep(more, more ? 2 : 0, 0, false);
-    kstep(more, more ? 2 : 0, 0, false);
     PS_MARK(ps_loop);
     PS_STEP(ps_kidx);
     if (!late) __builtin_amdgcn_s_barrier();
     PS_MARK(ps_align);
     PS_STEP(ps_kidx + 1);
-    // The ring slot of this tile's last K-step is free now (every wave has read it): the next tile's K-step 3 goes out
-    // BEFORE the stores.  Loads retire in order behind older stores, so a load issued after them would only count
-    // as landed once the stores have been acknowledged.
-    if (more) stage();
+    // The ring slots of this tile's last K-step(s) are free now (every wave has read them): the next tile's K-step 3
+    // (PAIR: K-steps 2 and 3) goes out BEFORE the stores.  Loads retire in order behind older stores, so a load issued
+    // after them would only count as landed once the stores have been acknowledged.
+    if (more) { if constexpr (PAIR) stage2(); else stage(); }
 
     // ---------------------------------------------------------------- epilogue (no LDS ring use, no barrier)
     // acc[i][j][r]: channel n = wn*WTN + i*16 + 4*fq + r, row m = wm*WTM + j*16 + fr of tile (c_tm, c_tn)
@@ -405,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, bool GEGLU>
+template <int BM, int BN, int WM, int WN, bool GEGLU, int VAR>
 int launch_ps_t(GemmArgs &a, hipStream_t s) {
 #ifdef SP_GEMM_EXPERIMENTS
   constexpr size_t lds = (size_t)SSTAGES * (BM + BN) * 64 + 8 * 3072 + 1024;   // + per-K-step stamps
@@ -414,14 +461,14 @@ int launch_ps_t(GemmArgs &a, hipStream_t s) {
 #endif
   static_assert(lds <= 160 * 1024, "LDS per workgroup");
   static bool attr_set[SP_MAX_DEVICES] = {};
-  if (int rc = sp_ensure_dyn_lds((const void *)gemm_ps_kernel<BM, BN, WM, WN, GEGLU>, (int)lds, attr_set, "sp_gemm_f16(ps)"))
+  if (int rc = sp_ensure_dyn_lds((const void *)gemm_ps_kernel<BM, BN, WM, WN, GEGLU, VAR>, (int)lds, attr_set, "sp_gemm_f16(ps)"))
     return rc;
   a.tiles_m = (a.m + BM - 1) / BM;
   a.tiles_n = a.n / BN;
   const int ntiles = a.tiles_m * a.tiles_n;
   const int grid = ntiles < 256 ? ntiles : 256;       // one workgroup per CU
   SP_CLEAR_STALE_ERROR();
-  hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WM, WN, GEGLU>), dim3(grid), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WM, WN, GEGLU, VAR>), dim3(grid), dim3(512), lds, s, a);
   SP_CHECK_LAUNCH("sp_gemm_f16(ps)");
   return SP_OK;
 }
@@ -443,9 +490,20 @@ bool ps_supported(const GemmArgs &a, int bm, int bn) {
   return true;
 }
 
+template <int VAR>
+int launch_ps_v(GemmArgs &a, int bm, hipStream_t s) {
+  if (a.geglu) return bm == 192 ? launch_ps_t<192, 256, 2, 4, true, VAR>(a, s) : launch_ps_t<256, 256, 2, 4, true, VAR>(a, s);
+  return bm == 192 ? launch_ps_t<192, 256, 2, 4, false, VAR>(a, s) : launch_ps_t<256, 256, 2, 4, false, VAR>(a, s);
+}
+
 int launch_ps(GemmArgs &a, int bm, int bn, hipStream_t s) {
-  if (a.geglu) return bm == 192 ? launch_ps_t<192, 256, 2, 4, true>(a, s) : launch_ps_t<256, 256, 2, 4, true>(a, s);
-  return bm == 192 ? launch_ps_t<192, 256, 2, 4, false>(a, s) : launch_ps_t<256, 256, 2, 4, false>(a, s);
+  // K >= 640: K-steps staged in pairs (+3-4 % on the FF contractions of the 32,256- and 8,064-row levels; at K = 320 a
+  // tile is 10 K-steps and the shorter prefetch distance of the pairs costs 4 %)
+  bool pair = a.k >= 20 * SBK && (a.k / SBK) % 2 == 0;
+#ifdef SP_GEMM_EXPERIMENTS
+  if (a.dbg & 16) pair = false;
+#endif
+  return pair ? launch_ps_v<1>(a, bm, s) : launch_ps_v<0>(a, bm, s);
 }
 
 }  // namespace spgemm

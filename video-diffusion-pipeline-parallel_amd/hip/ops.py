@@ -169,23 +169,27 @@ def groupnorm_ws_bytes(instances, rows, c, groups) -> int:
 
 
 def groupnorm(x, gamma, beta, y, *, instances, rows, c, groups, eps, silu, ws):
-    _check(load().sp_groupnorm_f16(_f16(x, "x").data_ptr(), _ptr(gamma), _ptr(beta), _f16(y, "y").data_ptr(),
-                                   instances, rows, c, groups, eps, int(silu), ws.data_ptr(),
-                                   ws.numel() * ws.element_size(), _stream()), "sp_groupnorm_f16")
+    # algorithmic bytes: statistics pass reads x, apply pass reads x and writes y (the single-launch path reads once)
+    with _Timed("groupnorm", 0.0, 3 * 2.0 * instances * rows * c):
+        _check(load().sp_groupnorm_f16(_f16(x, "x").data_ptr(), _ptr(gamma), _ptr(beta), _f16(y, "y").data_ptr(),
+                                       instances, rows, c, groups, eps, int(silu), ws.data_ptr(),
+                                       ws.numel() * ws.element_size(), _stream()), "sp_groupnorm_f16")
     return y
 
 
 def layernorm(x, gamma, beta, y, *, rows, c, eps=1e-5, addvec=None, addvec_rows=0, sum_out=None):
-    _check(load().sp_layernorm_f16(_f16(x, "x").data_ptr(), _ptr(addvec), addvec_rows, _ptr(sum_out),
-                                   gamma.data_ptr(), beta.data_ptr(), _f16(y, "y").data_ptr(), rows, c, eps,
-                                   _stream()), "sp_layernorm_f16")
+    with _Timed("layernorm", 0.0, (2 + (sum_out is not None)) * 2.0 * rows * c):
+        _check(load().sp_layernorm_f16(_f16(x, "x").data_ptr(), _ptr(addvec), addvec_rows, _ptr(sum_out),
+                                       gamma.data_ptr(), beta.data_ptr(), _f16(y, "y").data_ptr(), rows, c, eps,
+                                       _stream()), "sp_layernorm_f16")
     return y
 
 
 def ln_stats(x, stats, *, rows, c, eps=1e-5, addvec=None, addvec_rows=0, sum_out=None):
     """Per-row (mean, rstd) of a LayerNorm that the next GEMM applies itself (``gemm(..., ln_stats=, ln_colsum=)``)."""
-    _check(load().sp_ln_stats_f16(_f16(x, "x").data_ptr(), _ptr(addvec), addvec_rows, _ptr(sum_out), stats.data_ptr(),
-                                  rows, c, eps, _stream()), "sp_ln_stats_f16")
+    with _Timed("ln_stats", 0.0, (1 + (sum_out is not None)) * 2.0 * rows * c + 8.0 * rows):
+        _check(load().sp_ln_stats_f16(_f16(x, "x").data_ptr(), _ptr(addvec), addvec_rows, _ptr(sum_out),
+                                      stats.data_ptr(), rows, c, eps, _stream()), "sp_ln_stats_f16")
     return stats
 
 
@@ -213,9 +217,10 @@ def attn_spatial_fp8(q, k, v, o, workspace, *, ldq, ldk, ldv, ldo, batch, seq, h
 
 
 def attn_temporal(q, k, v, o, *, ldq, ldk, ldv, ldo, batch, frames, hw, heads, scale=0.125):
-    _check(load().sp_attn_temporal_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), ldq, ldk, ldv, ldo,
-                                       batch, frames, hw, heads, scale, zero_page(o.device).data_ptr(), _stream()),
-           "sp_attn_temporal_f16")
+    with _Timed("attn_temporal", 4.0 * batch * hw * heads * frames * frames * 64, 4 * 2.0 * batch * frames * hw * heads * 64):
+        _check(load().sp_attn_temporal_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), ldq, ldk, ldv, ldo,
+                                           batch, frames, hw, heads, scale, zero_page(o.device).data_ptr(), _stream()),
+               "sp_attn_temporal_f16")
     return o
 
 
@@ -232,8 +237,9 @@ def euler_step(latent, eps_cond, eps_uncond, guidance, out, *, ld_eps, sigma, si
 
 
 def concat_channels(a, ca, b, cb, out, rows):
-    _check(load().sp_concat_channels_f16(a.data_ptr(), ca, b.data_ptr(), cb, out.data_ptr(), rows, _stream()),
-           "sp_concat_channels_f16")
+    with _Timed("concat", 0.0, 2 * 2.0 * rows * (ca + cb)):
+        _check(load().sp_concat_channels_f16(a.data_ptr(), ca, b.data_ptr(), cb, out.data_ptr(), rows, _stream()),
+               "sp_concat_channels_f16")
     return out
 
 
