@@ -240,7 +240,9 @@ def test_gemm_temporal_conv(frames, hw, c):
                                               # single-launch register-resident path (>= 128 (instance, group) slabs):
                                               (14, 576, 1280, 1), (14, 2304, 640, 0), (14, 576, 2560, 1),
                                               (4, 700, 1920, 1), (14, 101, 640, 1), (8, 1632, 1280, 0),
-                                              (8, 1633, 1280, 0), (14, 144, 1280, 1)])
+                                              (8, 1633, 1280, 0), (14, 144, 1280, 1),
+                                              # small tensors normalised over all frames: single launch with 32 workgroups
+                                              (1, 2016, 1280, 1), (1, 2040, 1280, 0), (1, 2041, 1280, 0), (2, 2016, 1280, 1)])
 def test_groupnorm(inst, rows, c, silu):
     ops = _ops()
     g = torch.Generator().manual_seed(c + rows)
@@ -256,7 +258,7 @@ def test_groupnorm(inst, rows, c, silu):
 
 
 @pytest.mark.parametrize("inst,rows,c", [(2, 9216, 320), (1, 14 * 2304, 640), (14, 576, 1280), (14, 144, 2560),
-                                          (3, 1000, 960)])
+                                          (3, 1000, 960), (1, 2016, 1280)])
 def test_groupnorm_large_mean_small_variance(inst, rows, c):
     """Channels whose mean is ~50 standard deviations away from zero (real checkpoints have them): E[x^2] - mean^2 in
     fp32 would lose the variance.  Per-group offsets (some +, some -, some none) + a per-channel offset inside groups;
@@ -593,6 +595,13 @@ def test_gemv_batched():
     y16 = torch.empty(batch, rows, n, dtype=torch.float16, device=DEV)
     ops.gemv_batched(x_each.half().to(DEV), w.half().to(DEV), None, batch=batch, n=n, k=k, rows=rows, y16=y16, silu_out=True)
     check(y16, F.silu(torch.einsum("grk,gnk->grn", x_each, w)))
+    # n not a multiple of the 8 outputs a wave owns: nothing may be written past the last output
+    n2 = 203
+    w2 = h(torch.randn(n2, k, generator=g) / math.sqrt(k))
+    flat = torch.full((rows * n2 + 8,), 7.0, dtype=torch.float32, device=DEV)
+    ops.gemv(x_shared.half().to(DEV), w2.half().to(DEV), None, n=n2, k=k, rows=rows, y32=flat[:rows * n2].view(rows, n2))
+    check(flat[:rows * n2].view(rows, n2), x_shared @ w2.t(), l2=1e-5, mx=1e-5)
+    assert torch.all(flat[rows * n2:] == 7.0)
 
 
 def test_pack_input_and_euler():

@@ -83,43 +83,62 @@ __global__ void add_rowvec_kernel(const f16 *__restrict__ x, const float *__rest
   *(f16x8 *)(y + idx * 8) = v;
 }
 
-// one wave per output element n: y[row][n] = W[n][:] . act(x[row][:]) + b[n]
-// blockIdx.z = problem of a batch of same-shape GEMVs (strides in elements; 0 = shared operand)
+// y[row][n] = W[n][:] . act(x[row][:]) + b[n].  A wave owns RC consecutive output elements and has the RC weight rows
+// of a K slice in flight together (one output per wave kept a single 16-byte load per lane in flight: 0.3 TB/s on the
+// 77 MB of time-embedding projections).  blockIdx.z = problem of a batch of same-shape GEMVs (strides in elements;
+// 0 = shared operand)
+constexpr int GEMV_RC = 8;
 __global__ __launch_bounds__(256) void gemv_kernel(const f16 *__restrict__ x, int64_t ldx,
                                                    const f16 *__restrict__ w, const float *__restrict__ b,
                                                    float *__restrict__ y, f16 *__restrict__ yh, int64_t ldy,
                                                    int n, int k, int silu_in, int silu_out, int64_t xs,
                                                    int64_t ws, int64_t bs, int64_t ys) {
+  constexpr int RC = GEMV_RC;
   const int lane = threadIdx.x & 63;
-  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int col0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RC;
   const int row = blockIdx.y;
-  if (col >= n) return;
+  if (col0 >= n) return;
   const int64_t g = blockIdx.z;
   x += g * xs; w += g * ws;
   if (b) b += g * bs;
   if (y) y += g * ys;
   if (yh) yh += g * ys;
-  const f16 *wr = w + (int64_t)col * k;
   const f16 *xr = x + (int64_t)row * ldx;
-  float acc = 0.f;
+  const f16 *wr[RC];
+#pragma unroll
+  for (int c = 0; c < RC; ++c) wr[c] = w + (int64_t)min(col0 + c, n - 1) * k;   // (columns past n: recomputed, not stored)
+  float acc[RC];
+#pragma unroll
+  for (int c = 0; c < RC; ++c) acc[c] = 0.f;
   for (int i = lane * 8; i < k; i += 64 * 8) {
-    const f16x8 wv = *(const f16x8 *)(wr + i);
+    f16x8 wv[RC];
+#pragma unroll
+    for (int c = 0; c < RC; ++c) wv[c] = *(const f16x8 *)(wr[c] + i);
     const f16x8 xv = *(const f16x8 *)(xr + i);
+    float xf[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float xf = (float)xv[e];
+      xf[e] = (float)xv[e];
       // torch evaluates F.silu on the fp16 tensor: round the activation back to fp16
-      if (silu_in) xf = (float)(f16)silu_f(xf);
-      acc += xf * (float)wv[e];
+      if (silu_in) xf[e] = (float)(f16)silu_f(xf[e]);
     }
+#pragma unroll
+    for (int c = 0; c < RC; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[c] += xf[e] * (float)wv[c][e];
   }
-  acc = wave_sum(acc);
-  if (lane == 0) {
-    float v = acc + (b ? b[col] : 0.f);
-    if (silu_out) v = silu_f(v);
-    if (y) y[(int64_t)row * ldy + col] = v;
-    if (yh) yh[(int64_t)row * ldy + col] = (f16)v;
-  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int c = 0; c < RC; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
+#pragma unroll
+  for (int c = 0; c < RC; ++c)
+    if (lane == c && col0 + c < n) {
+      float v = acc[c] + (b ? b[col0 + c] : 0.f);
+      if (silu_out) v = silu_f(v);
+      if (y) y[(int64_t)row * ldy + col0 + c] = v;
+      if (yh) yh[(int64_t)row * ldy + col0 + c] = (f16)v;
+    }
 }
 
 __global__ void sinusoid_kernel(const float *__restrict__ vals, f16 *__restrict__ out, int count, int dim) {
@@ -194,7 +213,7 @@ extern "C" int sp_gemv_f16(const void *x, int64_t ldx, const void *w, const floa
   SP_REQUIRE(x && w && (y || y_f16), "sp_gemv_f16: null pointer");
   SP_REQUIRE(rows > 0 && n > 0 && k > 0 && k % 8 == 0 && ldx % 8 == 0, "sp_gemv_f16: bad shape rows=%d n=%d k=%d", rows, n, k);
   SP_CLEAR_STALE_ERROR();
-  hipLaunchKernelGGL(gemv_kernel, dim3((n + 3) / 4, rows), dim3(256), 0, (hipStream_t)stream, (const f16 *)x,
+  hipLaunchKernelGGL(gemv_kernel, dim3((n + 4 * GEMV_RC - 1) / (4 * GEMV_RC), rows), dim3(256), 0, (hipStream_t)stream, (const f16 *)x,
                      ldx, (const f16 *)w, b, y, (f16 *)y_f16, ldy, n, k, silu_in, silu_out, (int64_t)0, (int64_t)0,
                      (int64_t)0, (int64_t)0);
   SP_CHECK_LAUNCH("sp_gemv_f16");
@@ -210,7 +229,7 @@ extern "C" int sp_gemv_batched_f16(const void *x, int64_t ldx, int64_t x_stride,
                  x_stride % 8 == 0 && w_stride % 8 == 0,
              "sp_gemv_batched_f16: bad shape batch=%d rows=%d n=%d k=%d", batch, rows, n, k);
   SP_CLEAR_STALE_ERROR();
-  hipLaunchKernelGGL(gemv_kernel, dim3((n + 3) / 4, rows, batch), dim3(256), 0, (hipStream_t)stream, (const f16 *)x,
+  hipLaunchKernelGGL(gemv_kernel, dim3((n + 4 * GEMV_RC - 1) / (4 * GEMV_RC), rows, batch), dim3(256), 0, (hipStream_t)stream, (const f16 *)x,
                      ldx, (const f16 *)w, b, y, (f16 *)y_f16, ldy, n, k, silu_in, silu_out, x_stride, w_stride,
                      b_stride, y_stride);
   SP_CHECK_LAUNCH("sp_gemv_batched_f16");

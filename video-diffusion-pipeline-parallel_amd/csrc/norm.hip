@@ -455,13 +455,24 @@ extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *
     const int cpg = c / groups;
     hipStream_t fs = (hipStream_t)stream;
     // (an 8-byte-vector variant for 20/60 channels per group measured slower than the three-launch path)
-    if (cpg % 8 == 0 && cpg / 8 <= 512 && rows <= (int64_t)16 * (512 / (cpg / 8)) &&
-        (int64_t)instances * groups >= 128 && (int64_t)instances * groups <= 0x7fffffff) {   // >= 128 workgroups
+    // At least 128 workgroups -- or a tensor so small (<= 8 MB: the 2,016-row level normalised over all frames, 32
+    // workgroups) that three launches cost more than the 32 CUs' streaming time.
+    if (cpg % 8 == 0 && cpg / 8 <= 512 && (int64_t)instances * groups <= 0x7fffffff &&
+        ((int64_t)instances * groups >= 128 || (int64_t)instances * rows * c * 2 <= (8 << 20))) {
+      const int64_t rp = 512 / (cpg / 8);
       SP_CLEAR_STALE_ERROR();
-      hipLaunchKernelGGL((gn_fused_kernel<8, 16>), dim3(instances * groups), dim3(512), 0, fs, (const f16 *)x, gamma,
-                         beta, (f16 *)y, rows, c, groups, eps, fuse_silu);
-      SP_CHECK_LAUNCH("sp_groupnorm_f16(fused)");
-      return SP_OK;
+      if (rows <= 16 * rp) {
+        hipLaunchKernelGGL((gn_fused_kernel<8, 16>), dim3(instances * groups), dim3(512), 0, fs, (const f16 *)x, gamma,
+                           beta, (f16 *)y, rows, c, groups, eps, fuse_silu);
+        SP_CHECK_LAUNCH("sp_groupnorm_f16(fused)");
+        return SP_OK;
+      }
+      if (rows <= 20 * rp) {
+        hipLaunchKernelGGL((gn_fused_kernel<8, 20>), dim3(instances * groups), dim3(512), 0, fs, (const f16 *)x, gamma,
+                           beta, (f16 *)y, rows, c, groups, eps, fuse_silu);
+        SP_CHECK_LAUNCH("sp_groupnorm_f16(fused)");
+        return SP_OK;
+      }
     }
   }
   const int oc = c / 8;

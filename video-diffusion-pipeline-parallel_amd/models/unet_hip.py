@@ -187,6 +187,7 @@ class SVDUNetHIP:
         self._group_small_gemvs()
         self._gn_ws = None
         self._sk_ws = {}
+        self._pos_cache = {}
         self._fp8_ws = {}
 
     # ------------------------------------------------------------------ weight packing
@@ -269,6 +270,14 @@ class SVDUNetHIP:
             cv = torch.empty((g, r.b, c), dtype=torch.float32, device=dev)
             ops.gemv_batched(v16, sm["Wo"], sm["bo"], batch=g, n=c, k=c, rows=r.b, y32=cv)
             r.cross[c] = cv
+        # The frame position embeddings are a function of the weights and the frame count only (diffusers evaluates
+        # time_pos_embed(time_proj(arange(F))) in every forward): evaluated once per frame count, kept.
+        pos = self._pos_cache.get(r.f)
+        if pos is not None:
+            r.pos = pos
+            return
+        for c, sm in self._small.items():
+            t = sm["T"]
             sin = torch.empty((r.f, c), dtype=torch.float16, device=dev)
             ops.sinusoid(r.frame_ids, sin, r.f, c)
             pe_h = torch.empty((t, r.f, 4 * c), dtype=torch.float16, device=dev)
@@ -276,6 +285,9 @@ class SVDUNetHIP:
             pe = torch.empty((t, r.f, c), dtype=torch.float16, device=dev)
             ops.gemv_batched(pe_h, sm["W2"], sm["b2"], batch=t, n=c, k=4 * c, rows=r.f, y16=pe)
             r.pos[c] = pe
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(dev).synchronize()      # complete before a forward on another stream may read it
+            self._pos_cache[r.f] = r.pos
 
     def _transformer_params(self, sd, p, c):
         dev = self.device
