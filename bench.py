@@ -399,15 +399,20 @@ def main():
     # ---- per-kernel roofline of the dominant kernel, measured live with events on the launch stream
     if rank == 0 and not args.no_roofline:
         with torch.no_grad():
-            ops.PROFILE = []
             lat = supplier(0)
-            model(lat, 0)
-            torch.cuda.synchronize(device)
+            for _ in range(2):     # (profiled forwards run launch by launch, not as a graph replay: the first one
+                ops.PROFILE = []   #  re-populates the allocator and runs on a GPU the host keeps waiting; keep the second)
+                model(lat, 0)
+                torch.cuda.synchronize(device)
             prof, ops.PROFILE = ops.PROFILE, None
-        by = {}
-        for kind, fl, e0, e1, nb in prof:
+        by, shapes = {}, {}
+        for kind, fl, e0, e1, nb, tag in prof:
+            sec = e0.elapsed_time(e1) / 1e3
             acc = by.setdefault(kind, [0.0, 0.0, 0, 0.0])
-            acc[0] += fl; acc[1] += e0.elapsed_time(e1) / 1e3; acc[2] += 1; acc[3] += nb
+            acc[0] += fl; acc[1] += sec; acc[2] += 1; acc[3] += nb
+            if kind == "gemm":
+                sh = shapes.setdefault(tag, [0.0, 0.0, 0])
+                sh[0] += fl; sh[1] += sec; sh[2] += 1
         gf, gt, gn, gb = by["gemm"]
         # HBM/fabric bytes per launch come from PMC passes (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE) that
         # cannot run inside this process; they are collected with tools/pmc_forward.sh on a named commit and committed.
@@ -430,7 +435,11 @@ def main():
                            "algorithmic_bytes_per_launch": gb / gn,
                            "traffic_over_algorithmic": (traffic / (gb / gn)) if traffic else None,
                            "launches_per_forward": gn, "avg_launch_us": 1e6 * gt / gn,
-                           "flop_per_launch_avg": gf / gn}
+                           "flop_per_launch_avg": gf / gn,
+                           # the ten shapes with the most time: [rows, columns, channels per tap, gather mode, GEGLU]
+                           "top_shapes": [{"shape": list(k), "launches": v[2], "ms": round(1e3 * v[1], 3),
+                                           "tflops": round(v[0] / v[1] / 1e12, 1)}
+                                          for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:10]]}
         if "attn_spatial" in by:
             af, at, an, _ = by["attn_spatial"]
             out["roofline_attention"] = {"bound": "mfma", "kernel": "attn_spatial_kernel",

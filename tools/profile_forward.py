@@ -14,28 +14,20 @@ def main():
     model = StableVideoUNet.from_random_init(StableVideoUNet._default_timestep_schedule(25), seed=0, device=dev)
     model.set_dummy_conditioning(1, frames, 72, 128, dev)
     lat = torch.randn(1, 4, frames, 72, 128, device=dev, dtype=torch.float16) * model.init_noise_sigma
-    real_gemm = ops.gemm
-    shapes = []
-    def spy(a, w, out, **kw):
-        shapes.append((kw["m"], kw["n"], kw["cin"], kw.get("mode", 0), bool(kw.get("geglu"))))
-        return real_gemm(a, w, out, **kw)
     with torch.no_grad():
         model(lat, 0); model(lat, 1)
         torch.cuda.synchronize()
-        ops.gemm = spy
-        import vdpp_amd.models.unet_hip as uh
         ops.PROFILE = []
         t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
         t0.record(); model(lat, 2); t1.record()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
     print("forward ms (with event overhead):", t0.elapsed_time(t1))
-    gi = 0
     agg = collections.OrderedDict()
-    for kind, fl, e0, e1, _nb in prof:
+    for kind, fl, e0, e1, _nb, tag in prof:
         ms = e0.elapsed_time(e1)
         if kind == "gemm":
-            key = ("gemm",) + shapes[gi]; gi += 1
+            key = ("gemm",) + tag
         else:
             key = (kind, fl or _nb)
         a = agg.setdefault(key, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl; a[3] += _nb

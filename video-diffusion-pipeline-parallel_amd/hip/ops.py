@@ -20,13 +20,13 @@ class HipKernelError(RuntimeError):
 
 # Optional per-launch timing (bench.py roofline leg): when a list is installed here, the contraction
 # and attention wrappers bracket their launch with events on the launching stream and append
-# (kind, flops, start_event, end_event, algorithmic_bytes).
+# (kind, flops, start_event, end_event, algorithmic_bytes, tag) -- tag: the shape of a contraction, else None.
 PROFILE = None
 
 
 class _Timed:
-    def __init__(self, kind, flops, nbytes=0.0):
-        self.kind, self.flops, self.nbytes = kind, flops, nbytes
+    def __init__(self, kind, flops, nbytes=0.0, tag=None):
+        self.kind, self.flops, self.nbytes, self.tag = kind, flops, nbytes, tag
 
     def __enter__(self):
         if PROFILE is not None:
@@ -38,7 +38,7 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.nbytes))
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.nbytes, self.tag))
         return False
 
 
@@ -114,7 +114,7 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
     # algorithmic bytes of this launch: every operand element once (A without tap re-reads), output and residuals once
     a_rows = d.n_img * d.hin * d.win if mode == A_CONV3X3 else m
     nbytes = 2.0 * (a_rows * cin + n * taps * cin + m * (n_store or nout) * (1 + (res1 is not None) + (res2 is not None)))
-    with _Timed("gemm", 2.0 * m * n * taps * cin, nbytes):
+    with _Timed("gemm", 2.0 * m * n * taps * cin, nbytes, (m, n, cin, mode, bool(geglu))):
         _check(load().sp_gemm_f16(ctypes.byref(d), _stream()), "sp_gemm_f16")
     return out
 
