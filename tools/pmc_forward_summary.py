@@ -53,6 +53,9 @@ if len(sys.argv) > 2:
             rd += 2 * tables["fetch"][k]["FETCH_SIZE"] * 1024
             wr += tables["write"][k]["WRITE_SIZE"] * 1024
             n += tables["fetch"][k]["n"]
+        elif "splitk_reduce" in k:          # second half of a split-K contraction: its bytes count, not its launch
+            rd += 2 * tables["fetch"][k]["FETCH_SIZE"] * 1024
+            wr += tables["write"][k]["WRITE_SIZE"] * 1024
     json.dump({"source": "tools/pmc_forward.sh + tools/pmc_forward_summary.py (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                          "passes over the two UNet forwards of tools/one_forward.py = second half of the dispatches)",
                "kernel": "implicit-GEMM kernels (gemm_pp_kernel<*>, gemm_ps_kernel<*>, gemm_f16_kernel<*>)",
