@@ -148,6 +148,8 @@ def cpu_baseline(frames_full, h, w, total_steps):
 def _sim_worker(rank, ws, init_file, out_file, c, hid, shape, steps, reps, threads):
     import logging
 
+    os.dup2(2, 1)       # Gloo announces its peers on stdout; the parent's stdout carries exactly one JSON line
+
     from vdpp_amd.models import DummyUNet
     from vdpp_amd.pipeline import run_single_latent
 
