@@ -64,3 +64,19 @@ def test_production_mode_runs_the_svd_pipeline(monkeypatch, tmp_path, caplog):
     norms = [float(m.group(1)) for m in re.finditer(r"final latent norm: ([0-9.eE+-]+)", caplog.text)]
     assert len(norms) == 2 and all(n > 0 and n == n and n != float("inf") for n in norms)
     assert not torch.distributed.is_initialized()
+
+
+def test_rccl_grouped_p2p_on_a_side_stream_single_rank_self_loop():
+    """The only RCCL execution a one-GPU box allows (RCCL refuses two ranks on one device): a single-rank NCCL group
+    whose rank sends a latent to itself with ONE grouped isend + irecv on a side stream, ordered against the compute
+    stream with events and record_stream exactly as the ring hand-off in pipeline._run_many_ring does.  Own process:
+    the test session's process groups are Gloo."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_selfloop.py")], env=env, timeout=180,
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "self-loop p2p ok" in res.stdout and "backend nccl" in res.stdout
