@@ -230,8 +230,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     n = world
     conc = max(1, args.concurrent if args.concurrent is not None else 2)
-    # N>1: 8N videos so that filling/draining the pipe (N-1 stage times inside the bracketed region) stays small
-    steps = args.steps if args.steps is not None else (4 * conc if n == 1 else max(8 * n, 2 * conc))
+    # N>1: 16N videos so that filling/draining the chain (N-1 stage times inside the bracketed region: the barriers on
+    # both sides drain it) stays near 5 % (8N: 10 % at N = 8); ~20 s at every N
+    steps = args.steps if args.steps is not None else (4 * conc if n == 1 else max(16 * n, 2 * conc))
     warmup = args.warmup if args.warmup is not None else (conc if n == 1 else max(n, conc))
 
     if os.environ.get("VDPP_SHARE_GPU") == "1":
