@@ -44,7 +44,7 @@ def run(spec, iters=20, rounds=5):
                 torch.cuda.synchronize()
                 if r == 0:
                     if ref is None: ref = out.float().clone()
-                    else: assert torch.equal(out.float(), ref), (spec, arm, float((out.float() - ref).abs().max()))
+                    elif not os.environ.get("NOCHECK"): assert torch.equal(out.float(), ref), (spec, arm, float((out.float() - ref).abs().max()))
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(iters): ops.gemm(a, wt, out, **kw)

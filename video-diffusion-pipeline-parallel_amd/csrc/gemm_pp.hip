@@ -257,8 +257,16 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
   constexpr int B_LOADS_HI = B_PIECES / NWV;              // the other waves
   constexpr int B_SPLIT = B_PIECES % NWV == 0 ? NWV : B_PIECES % NWV;   // waves below this index take B_LOADS_LO
   static_assert((B_SPLIT == NWV || B_SPLIT == 4) && (A_SPLIT == NWV || A_SPLIT == 4), "wave halves must have uniform DMA counts");
+#ifdef SP_GEMM_EXPERIMENTS
+  // (EXP & 16, timing only, results are wrong: activation pieces are issued for tap 0 only -- the DMA-instruction
+  // count of a kernel that keeps a halo tile of the activations in LDS; the waits count weight pieces only)
+  constexpr bool HALO_COUNT = (EXP & 16) != 0;
+  constexpr int L_EARLY = (HALO_COUNT ? 0 : A_LOADS) + B_LOADS_LO;
+  constexpr int L_LATE = (HALO_COUNT ? 0 : (A_SPLIT == NWV ? A_LOADS : A_LOADS_HI)) + (B_SPLIT == NWV ? B_LOADS_LO : B_LOADS_HI);
+#else
   constexpr int L_EARLY = A_LOADS + B_LOADS_LO;   // waves 0-3
   constexpr int L_LATE = (A_SPLIT == NWV ? A_LOADS : A_LOADS_HI) + (B_SPLIT == NWV ? B_LOADS_LO : B_LOADS_HI);   // waves 4-7
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -372,12 +380,13 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
     bptr[j] = p.w + (int64_t)n * p.k + (lchunk ^ swz4(r)) * 8;
   }
 
+  bool skip_a = false;                            // (experiments build: see HALO_COUNT)
   auto stage = [&](int slot) {
     char *sa = smem + slot * STAGE;
     char *sb = sa + A_BYTES;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-      if (i < A_LOADS_HI || wave < A_SPLIT) {     // wave-uniform
+      if ((i < A_LOADS_HI || wave < A_SPLIT) && !skip_a) {     // wave-uniform
         glds16(aptr[i], sa + (i * NWV + wave) * 1024);
         aptr[i] += astep[i];
       }
@@ -423,6 +432,9 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
   int staged = 0, in_tap = 0, tap = 0, stage_slot = 0, read_slot = 0;
   auto stage_next = [&]() {
     if (in_tap == cpt) { ++tap; in_tap = 0; set_tap(tap); }
+#ifdef SP_GEMM_EXPERIMENTS
+    if constexpr ((EXP & 16) != 0) skip_a = tap > 0;
+#endif
     stage(stage_slot);
     stage_slot = stage_slot + 1 == PSTAGES ? 0 : stage_slot + 1;
     ++staged; ++in_tap;
@@ -621,6 +633,11 @@ int launch_pp(GemmArgs &a, int bm, int bn, hipStream_t s) {
   }
   if (bm == 256 && bn == 320 && a.dbg == 4) return launch_pp<256, 320, 4>(a, s);
   if (bm == 192 && bn == 256 && a.dbg == 4) return launch_pp<192, 256, 4>(a, s);
+  if (a.dbg == 16) {
+    if (bm == 256 && bn == 256) return launch_pp<256, 256, 16>(a, s);
+    if (bm == 256 && bn == 320) return launch_pp<256, 320, 16>(a, s);
+    if (bm == 192 && bn == 256) return launch_pp<192, 256, 16>(a, s);
+  }
   if (a.dbg == 8) {
     if (bm == 256 && bn == 256) return launch_pp<256, 256, 8>(a, s);
     if (bm == 256 && bn == 320) return launch_pp<256, 320, 8>(a, s);
