@@ -10,7 +10,7 @@ import vdpp_amd  # noqa
 from vdpp_amd.hip import ops
 
 ARMS = [("auto", (0, 0, 0)), ("pp", (2, 0, 0)), ("ps256", (3, 256, 0)), ("ps192", (3, 192, 0))]
-SPLITK_ARMS = [("small", (1, 0, 0)), ("pp", (2, 0, 0)), ("split-K", (4, 0, 0)), ("auto+ws", (0, 0, 0))]   # m <= 2560
+SPLITK_ARMS = [("small", (1, 0, 0)), ("128x64", (1, 128, 0)), ("split-K", (4, 0, 0)), ("auto+ws", (0, 0, 0))]   # m <= 2560
 
 
 def run(spec, iters=20, rounds=4):

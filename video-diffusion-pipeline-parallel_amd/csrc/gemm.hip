@@ -531,6 +531,7 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
   }
   if (d->m <= 2560 && route != 2) {   // few rows (the 2016-row level): small tiles so the grid still covers 256 CUs
     if (d->n >= 3840 && n128) return launch<128, 128, 2, 2, 2>(a, s);
+    if (route == 1 && g_route_bm == 128) return launch<128, 64, 2, 2, 2>(a, s);     // (micro-benchmarks)
     return launch<64, 64, 2, 2, 3>(a, s);
   }
   // ---- large ping-pong tiles (gemm_pp.hip) for every N that is a multiple of 256 or 320
