@@ -434,7 +434,9 @@ def test_layernorm(rows, c):
     check(y, F.layer_norm(xs, (c,), gamma, beta))
 
 
-@pytest.mark.parametrize("batch,seq,heads", [(2, 128, 1), (3, 200, 2), (1, 6, 1), (2, 576, 5), (1, 1000, 3), (1, 2304, 2)])
+@pytest.mark.parametrize("batch,seq,heads", [(2, 128, 1), (3, 200, 2), (1, 6, 1), (2, 576, 5), (1, 1000, 3), (1, 2304, 2),
+                                              # >= 1,024 keys: the slot-structured 256-query kernel (ragged keys and queries)
+                                              (1, 1024, 1), (2, 1100, 2), (1, 1281, 3), (1, 1025, 1), (1, 4097, 1)])
 def test_attention_spatial(batch, seq, heads):
     ops = _ops()
     g = torch.Generator().manual_seed(seq)
@@ -449,14 +451,17 @@ def test_attention_spatial(batch, seq, heads):
     check(o, ref, l2=3e-3, mx=2e-2)
 
 
-def test_attention_spatial_online_softmax_rescale():
-    """Force a late maximum: one key far down the sequence dominates (exercises the rescale branch)."""
+@pytest.mark.parametrize("seq", [700, 1500])
+def test_attention_spatial_online_softmax_rescale(seq):
+    """Force a late maximum: one key far down the sequence dominates (exercises the rescale branch; 1,500 keys: of the
+    slot-structured kernel)."""
     ops = _ops()
     g = torch.Generator().manual_seed(1)
-    seq, c = 700, 64
+    c = 64
     q = h(torch.randn(seq, c, generator=g)); k = h(torch.randn(seq, c, generator=g)); v = h(torch.randn(seq, c, generator=g))
-    k[650] = q[5] * 3.0
+    k[seq - 50] = q[5] * 3.0
     k[130] = q[77] * 2.0
+    k[seq // 2] = q[300] * 2.5
     o = torch.empty(seq, c, dtype=torch.float16, device=DEV)
     ops.attn_spatial(q.half().to(DEV), k.half().to(DEV), v.half().to(DEV), o, ldq=c, ldk=c, ldv=c, ldo=c, batch=1, seq=seq, heads=1)
     ref = F.scaled_dot_product_attention(q[None, None], k[None, None], v[None, None])[0, 0]
