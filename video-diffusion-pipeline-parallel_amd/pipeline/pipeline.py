@@ -100,6 +100,13 @@ class _NullCtx:
         return False
 
 
+def _gloo_moves_gpu_tensor(t: torch.Tensor) -> bool:
+    """Gloo stages a GPU tensor through the host with no regard for the HIP stream that is still producing it (found
+    with tools/pp_equivalence.py: rank 1 received the latent of two steps earlier).  RCCL sends are stream-ordered;
+    for the Gloo rehearsal mode (PIPELINE_BACKEND=gloo with GPU latents) the producing stream is drained first."""
+    return t.is_cuda and dist.is_initialized() and dist.get_backend() == "gloo"
+
+
 class _SideStreamLink:
     """RCCL send/recv on a side HIP stream, fenced against the compute stream(s) by events.
 
@@ -226,6 +233,8 @@ class PipelineStage:
         if self._link is not None:
             self._link.send(latent)
         else:
+            if _gloo_moves_gpu_tensor(latent):
+                torch.cuda.current_stream(latent.device).synchronize()
             dist.send(latent, dst=downstream, tag=self.config.send_tag)
 
     # ------------------------------------------------------------------ compute
@@ -385,6 +394,8 @@ class PipelineStage:
             if cuda:
                 side = self._ring_stream
                 for j, t in outgoing:
+                    if _gloo_moves_gpu_tensor(t):
+                        self._streams[j].synchronize()
                     ev = torch.cuda.Event(); ev.record(self._streams[j]); side.wait_event(ev)
                     t.record_stream(side)
                 with torch.cuda.stream(side):
@@ -463,6 +474,8 @@ class PipelineStage:
         else:
             for i in sorted(finished):
                 ops.append(dist.P2POp(dist.isend, finished[i], last))
+        if ops and cuda and dist.get_backend() == "gloo":
+            torch.cuda.synchronize(dev)              # (see _gloo_moves_gpu_tensor)
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
