@@ -474,7 +474,7 @@ class PipelineStage:
         else:
             for i in sorted(finished):
                 ops.append(dist.P2POp(dist.isend, finished[i], last))
-        if ops and cuda and dist.get_backend() == "gloo":
+        if ops and cuda and dist.is_initialized() and dist.get_backend() == "gloo":
             torch.cuda.synchronize(dev)              # (see _gloo_moves_gpu_tensor)
         if ops:
             for w in dist.batch_isend_irecv(ops):
