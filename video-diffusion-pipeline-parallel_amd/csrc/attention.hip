@@ -191,17 +191,16 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
     // P -> fp16 pairwise (v_cvt_pk_f16_f32, round-to-nearest: one instruction per pair instead of two converts
     // and a pack)
     u32x4 pw[2][2];                                   // pw[kt][s] = the 8 fp16 P values of k-step s, as four packed pairs
-    float lsum = 0.f;
+    f32x2 lsum2[2] = {{0.f, 0.f}, {0.f, 0.f}};        // two independent packed chains (v_pk_add_f32), folded once per tile
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
-        const float p0 = fast_exp2(sacc[kt][e]);
-        const float p1 = fast_exp2(sacc[kt][e + 1]);
-        lsum += p0 + p1;
-        pw[kt][e >> 3][(e & 7) >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){p0, p1}, f16x2));
+        const f32x2 p = {fast_exp2(sacc[kt][e]), fast_exp2(sacc[kt][e + 1])};
+        lsum2[kt] += p;
+        pw[kt][e >> 3][(e & 7) >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, f16x2));
       }
-    l_run += lsum;
+    l_run += (lsum2[0][0] + lsum2[0][1]) + (lsum2[1][0] + lsum2[1][1]);
 
     // ---- O^T += V^T . P^T : the 8 transposed reads of one d-tile go out together (inline asm, own lgkmcnt wait)
     {
