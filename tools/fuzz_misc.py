@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised cross-checks of the attention and normalisation kernels against fp32 torch (CPU), with guard rows around
-every output (no write outside the rows the call owns).  usage: fuzz_misc.py [cases] [seed]"""
+"""Randomised cross-checks of the attention, normalisation, LayerNorm-statistics and GEMV kernels against fp32 / fp64
+torch (CPU), with guard rows around every output (no write outside the rows the call owns).
+usage: fuzz_misc.py [cases] [seed]"""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -37,7 +38,8 @@ def attn_spatial(rng, g, fp8):
     batch, heads = rng.choice([1, 2, 5]), rng.choice([1, 2, 5])
     seq = rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 200, 577, 1000, 1153])
     c = heads * 64
-    qkv = h(torch.randn(batch * seq, 3 * c, generator=g) * rng.choice([0.5, 1.0, 2.0]))
+    amp = rng.choice([0.5, 1.0, 2.0])
+    qkv = h(torch.randn(batch * seq, 3 * c, generator=g) * amp)
     d = qkv.half().to(DEV)
     buf, o = guarded(batch * seq, c)
     kw = dict(ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=batch, seq=seq, heads=heads)
@@ -45,7 +47,10 @@ def attn_spatial(rng, g, fp8):
         ws = torch.empty(ops.attn_fp8_ws_bytes(batch, seq, heads), dtype=torch.uint8, device=DEV)
         ops.attn_spatial_fp8(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o, ws, **kw)
         x = qkv.clamp(-448, 448).to(torch.float8_e4m3fn).float()
-        tol = 3e-2
+        # 3e-2 is the budget at unit-variance inputs (2.2e-2 from rounding P to e4m3); at twice the amplitude
+        # the softmax is peaked, a handful of 3-bit-mantissa probabilities carry a row and their rounding averages less
+        # (likewise short rows: fewer rounded probabilities per output)
+        tol = 3e-2 if (amp <= 1.0 and seq >= 256) else 4e-2
     else:
         ops.attn_spatial(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o, **kw)
         x, tol = qkv, 3e-3
@@ -111,8 +116,60 @@ def layernorm(rng, g):
     return e
 
 
+def ln_stats(rng, g):
+    rows = rng.choice([1, 3, 257, 4095, 4097, 8191, 8193, 9000, 20001])      # around the row-count thresholds of the
+    c = rng.choice([64, 320, 640, 960, 1280])                                 # lane-group kernels (8192 / 4096 / 2048)
+    x = h(torch.randn(rows, c, generator=g) * rng.choice([0.5, 3.0]) + 4.0 * torch.randn(rows, 1, generator=g))
+    add = rng.random() < 0.4
+    per = rng.choice([1, 50, 333])
+    xd = x.half().to(DEV)
+    st = torch.full((rows + 2, 2), -7.0, device=DEV)
+    kw = {}
+    if add:
+        av = h(torch.randn((rows + per - 1) // per, c, generator=g))
+        buf, sm = guarded(rows, c)
+        kw = dict(addvec=av.half().to(DEV), addvec_rows=per, sum_out=sm)
+        x = (x + av.repeat_interleave(per, 0)[:rows]).half().float()
+    ops.ln_stats(xd, st[1:rows + 1], rows=rows, c=c, eps=1e-5, **kw)
+    torch.cuda.synchronize()
+    what = f"ln_stats rows={rows} c={c} add={add}"
+    assert torch.all(st[0] == -7.0) and torch.all(st[rows + 1] == -7.0), "guard rows written: " + what
+    if add:
+        assert torch.equal(check_guard(buf, rows, what), x), "sum_out: " + what
+    xd64 = x.double()
+    got = st[1:rows + 1].cpu().double()
+    assert float((got[:, 0] - xd64.mean(1)).abs().max()) < 1e-4, what
+    e = rel_l2(got[:, 1], (xd64.var(1, unbiased=False) + 1e-5).rsqrt())
+    assert e <= 1e-5, f"rstd rel_l2={e:.3e}: {what}"
+    return e
+
+
+def gemv(rng, g):
+    batch, rows = rng.choice([1, 1, 3, 12]), rng.choice([1, 1, 2, 14])
+    n, k = rng.choice([1, 7, 8, 9, 200, 203, 320, 1280, 5120]), rng.choice([64, 320, 1024, 1280])
+    w = h(torch.randn(batch, n, k, generator=g) / k ** 0.5); b = torch.randn(batch, n, generator=g)
+    shared = rng.random() < 0.5
+    x = h(torch.randn(rows, k, generator=g)) if shared else h(torch.randn(batch, rows, k, generator=g))
+    silu_in, silu_out = rng.random() < 0.3, rng.random() < 0.3
+    xin = F.silu(x).half().float() if silu_in else x
+    ref = (torch.einsum("rk,gnk->grn", xin, w) if shared else torch.einsum("grk,gnk->grn", xin, w)) + b[:, None, :]
+    if silu_out: ref = F.silu(ref)
+    flat = torch.full((batch * rows * n + 16,), 7.0, dtype=torch.float32, device=DEV)
+    y = flat[8:8 + batch * rows * n].view(batch, rows, n)
+    ops.gemv_batched(x.half().to(DEV), w.half().to(DEV), b.to(DEV), batch=batch, n=n, k=k, rows=rows,
+                     x_stride=0 if shared else None, y32=y, silu_in=silu_in, silu_out=silu_out)
+    torch.cuda.synchronize()
+    what = f"gemv batch={batch} rows={rows} n={n} k={k} shared={shared} silu={silu_in}/{silu_out}"
+    assert torch.all(flat[:8] == 7.0) and torch.all(flat[8 + batch * rows * n:] == 7.0), "guard written: " + what
+    e = rel_l2(y.cpu(), ref)
+    assert e <= 2e-3, f"rel_l2={e:.3e}: {what}"
+    return e
+
+
 def one(rng, g):
-    kind = rng.choice(["as", "as", "as8", "at", "gn", "gn", "ln"])
+    kind = rng.choice(["as", "as", "as8", "at", "gn", "gn", "ln", "lns", "lns", "gv"])
+    if kind == "lns": return ln_stats(rng, g)
+    if kind == "gv": return gemv(rng, g)
     if kind == "as": return attn_spatial(rng, g, False)
     if kind == "as8": return attn_spatial(rng, g, True)
     if kind == "at": return attn_temporal(rng, g)
