@@ -169,7 +169,13 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
 #pragma unroll
     for (int e = 3; e < 31; e += 2) mt = fmaxf(fmaxf(mt, sacc[e >> 4][e & 15]), sacc[(e + 1) >> 4][(e + 1) & 15]);
     mt = fmaxf(mt, sacc[1][15]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    {   // the other 32 keys of this query column live 32 lanes away: v_permlane32_swap (a VALU exchange; __shfl_xor is a
+        // ds_bpermute round trip through the LDS crossbar with an lgkmcnt wait in the middle of the tile).  Inline asm:
+        // with the builtin hipcc (ROCm 7.2) uses only the first result when both operands hold the same value.
+      float ma = mt, mb = mt;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+      mt = fmaxf(ma, mb);                 // ma = {own lower, other lower}, mb = {other upper, own upper}
+    }
     // mt = (tile maximum) - m_run.  The first tile defines the reference; later tiles raise it only when a score
     // exceeds it by more than RESCALE_LOG2 (p = 2^(s - m) <= 2^8 is exact in fp16 relative precision and l, O are fp32):
     // with 32 query columns per wave SOME column would otherwise move in most tiles and make the whole wave rescale.
