@@ -30,12 +30,23 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+# NOTHING that can initialise the GPU is imported at module level: with `--gpus N` and no launcher the parent only
+# starts N fresh ranks (launch_ranks, stdlib only) and relays their output; torch and the package are imported by
+# _imports() inside the ranks (tests/test_bench_launcher_cpu.py pins this).
+torch = dist = None
 
-import vdpp_amd  # noqa: E402,F401
-from vdpp_amd.distributed import finalize_distributed, init_distributed, resolve_backend  # noqa: E402
-from vdpp_amd.pipeline import LatentSpec, PipelineConfig, PipelineStage, stage_sizes  # noqa: E402
+
+def _imports():
+    global torch, dist, finalize_distributed, init_distributed, resolve_backend
+    global LatentSpec, PipelineConfig, PipelineStage, stage_sizes
+    import torch as _torch
+    import torch.distributed as _dist
+
+    import vdpp_amd  # noqa: F401
+    from vdpp_amd.distributed import finalize_distributed, init_distributed, resolve_backend
+    from vdpp_amd.pipeline import LatentSpec, PipelineConfig, PipelineStage, stage_sizes
+    torch, dist = _torch, _dist
+
 
 PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 FRAMES, LAT_H, LAT_W, TOTAL_STEPS = 14, 72, 128, 25
@@ -79,7 +90,8 @@ def describe_rank(rank, n, device, ring, rotating, conc, selftest):
     sched = "single GPU" if n == 1 else ("ring" if ring else "chain" + (" + rotating extra step" if rotating else ""))
     print(f"[rank {rank}/{n}] device {device} ({torch.cuda.get_device_name(device)}), torch {torch.__version__}, "
           f"backend {backend}, RCCL {rccl}, schedule {sched}, {conc} videos in flight, ring self-test: {selftest}, "
-          f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}", file=sys.stderr, flush=True)
+          f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, "
+          f"NCCL_MAX_P2P_NCHANNELS={os.environ.get('NCCL_MAX_P2P_NCHANNELS')}", file=sys.stderr, flush=True)
 
 
 def parse():
@@ -141,6 +153,7 @@ def cpu_baseline(frames_full, h, w, total_steps):
     videos_per_s = 1.0 / (dt * scale * total_steps)
     del ref
     return {"value": videos_per_s, "unit": "videos/s", "cores": threads, "host_cores": cores, "kind": "port",
+            "extrapolated": True,
             "sample": f"oracle fp32 UNet (torch CPU), 1 forward at {sample_frames} of {frames_full} frames "
                       f"{h}x{w} in {dt:.1f}s, scaled by FLOP ratio {scale:.2f} x {total_steps} steps"}
 
@@ -149,6 +162,7 @@ def _sim_worker(rank, ws, init_file, out_file, c, hid, shape, steps, reps, threa
     import logging
 
     os.dup2(2, 1)       # Gloo announces its peers on stdout; the parent's stdout carries exactly one JSON line
+    _imports()
 
     from vdpp_amd.models import DummyUNet
     from vdpp_amd.pipeline import run_single_latent
@@ -221,13 +235,108 @@ def cpu_simulator():
     return out
 
 
+def visible_gpus():
+    """GPUs this process tree can use, WITHOUT touching the HIP runtime: KFD topology nodes with SIMDs, narrowed by the
+    *_VISIBLE_DEVICES lists.  None if the topology cannot be read (the ranks themselves check again with torch)."""
+    import glob
+    nodes = 0
+    try:
+        for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            for line in open(prop):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    nodes += 1
+    except OSError:
+        return None
+    if nodes == 0:
+        return None if not os.path.isdir("/sys/class/kfd/kfd/topology/nodes") else 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is not None:
+            nodes = min(nodes, len([v for v in val.split(",") if v.strip() != ""]))
+    return nodes
+
+
+def p2p_env(env):
+    """RCCL settings of the 1-2 MB stage-to-stage hand-off.  A receive posted ahead of its sender is a resident RCCL
+    kernel that holds one workgroup per P2P channel; the persistent GEMM wants one 160-KB-LDS workgroup on every
+    CU, so the hand-off gets two channels (a 1 MB message over one xGMI link needs no more) unless the caller says
+    otherwise.  Returned dict = what was in force (printed by every rank)."""
+    env.setdefault("NCCL_MAX_P2P_NCHANNELS", "2")
+    env.setdefault("NCCL_MIN_P2P_NCHANNELS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC is the only one this driver supports
+    return {k: env.get(k) for k in ("NCCL_MAX_P2P_NCHANNELS", "NCCL_MIN_P2P_NCHANNELS", "NCCL_MAX_NCHANNELS",
+                                    "HSA_ENABLE_IPC_MODE_LEGACY")}
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (ref scripts/benchmark_comparison.sh:85-120 wraps
+    every GPU count in torchrun; so does this): start `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a FRESH child process (never an exec; this parent has not touched the GPU and never will), pass the ranks'
+    stderr through, relay rank 0's JSON line as the only stdout line, and return the child's exit status."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    have = visible_gpus()
+    shared = os.environ.get("VDPP_SHARE_GPU") == "1"
+    if have is not None and have < n and not shared:
+        print(f"bench.py: --gpus {n} but {have} GPU(s) are visible to this process (KFD topology / *_VISIBLE_DEVICES); "
+              f"refusing to run a smaller job under the name of a larger one.  (Rehearsal on fewer cards: "
+              f"VDPP_SHARE_GPU=1 PIPELINE_BACKEND=gloo.)", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env["VDPP_BENCH_LAUNCHED_BY_PARENT"] = "1"
+    p2p_env(env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"bench.py: WORLD_SIZE is unset; starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line_out = None
+    for line in proc.stdout:
+        txt = line.strip()
+        is_result = False
+        if txt.startswith("{"):
+            try:
+                is_result = "metric" in json.loads(txt)
+            except ValueError:
+                pass
+        if is_result:
+            line_out = txt
+        else:
+            sys.stderr.write(line)      # anything else a rank wrote to stdout (Gloo's peer announcements, ...)
+    rc = proc.wait()
+    if rc == 0 and line_out is None:
+        print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
+        rc = 4
+    if line_out is not None and rc == 0:
+        print(line_out, flush=True)
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        # never report one job size under the name of another
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} "
+                         f"(or plain `python bench.py --gpus {args.gpus}`, which starts its own ranks)")
+    rccl_env = p2p_env(os.environ) if world > 1 else {}
+    _imports()
+    shared = os.environ.get("VDPP_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < world and not shared:
+        raise SystemExit(f"bench.py: --gpus {world} but torch sees {have} device(s); refusing to run (rehearsal on fewer "
+                         f"cards: VDPP_SHARE_GPU=1 PIPELINE_BACKEND=gloo)")
     n = world
     conc = max(1, args.concurrent if args.concurrent is not None else 2)
     # N>1: 16N videos so that filling/draining the chain (N-1 stage times inside the bracketed region: the barriers on
@@ -235,7 +344,7 @@ def main():
     steps = args.steps if args.steps is not None else (4 * conc if n == 1 else max(16 * n, 2 * conc))
     warmup = args.warmup if args.warmup is not None else (conc if n == 1 else max(n, conc))
 
-    if os.environ.get("VDPP_SHARE_GPU") == "1":
+    if shared:
         # rehearsal only (PIPELINE_BACKEND=gloo on a one-GPU box): ranks share the cards that exist; RCCL refuses this
         local_rank %= max(1, torch.cuda.device_count())
     device = torch.device(f"cuda:{local_rank}")
@@ -248,6 +357,17 @@ def main():
         dog.beat("first barrier")
         dist.barrier()      # create the world communicator collectively, before the first grouped send/recv needs it
         dog.beat("model construction")
+    # what the process group itself saw (the JSON line reports THIS, not the --gpus argument)
+    me = {"rank": rank, "device": str(device), "name": torch.cuda.get_device_name(device),
+          "uuid": str(getattr(torch.cuda.get_device_properties(device), "uuid", ""))}
+    ranks_seen = [me]
+    if n > 1:
+        ranks_seen = [None] * n
+        dist.all_gather_object(ranks_seen, me)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        if not shared and len({(r["device"], r["uuid"]) for r in ranks_seen}) != n:
+            raise SystemExit(f"bench.py: {n} ranks but they do not sit on {n} distinct devices: {ranks_seen}")
 
     from vdpp_amd.models.unet_spec import UNetConfig, forward_flops
     from vdpp_amd.hip import ops
@@ -321,6 +441,7 @@ def main():
             stage.drain()
         dog.beat("fence before the timed region")
         fence()
+        torch.cuda.reset_peak_memory_stats(device)      # ref src/modes/benchmark.py:240-249: peak of the timed region
         done_events = []
 
         def on_done(_idx):   # runs on the finishing sample's stream, right after its last step was enqueued
@@ -336,8 +457,11 @@ def main():
         elapsed = time.perf_counter() - t0
     dog.beat("reduction of the timings")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    peaks = [torch.cuda.max_memory_allocated(device) / 2**30]
     if n > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        peaks = [None] * n
+        dist.all_gather_object(peaks, torch.cuda.max_memory_allocated(device) / 2**30)
     elapsed = float(tmax.item())
 
     # steady-state figure in the reference's definition (benchmark.py:254-267): successive completion
@@ -371,6 +495,10 @@ def main():
         out = {
             "metric": "steady-state videos/sec (whole node), SVD 14f x 25step",
             "value": value, "unit": "videos/s", "n_gpus": n, "steps": steps, "warmup": warmup,
+            "world_size_seen_by_process_group": dist.get_world_size() if n > 1 else 1,
+            "backend": dist.get_backend() if n > 1 else "none", "ranks": ranks_seen, "rccl_env": rccl_env,
+            "gpus_shared_between_ranks": bool(shared and n > 1),
+            "peak_memory_gb_per_rank": [round(m, 3) for m in peaks], "max_peak_memory_gb": round(max(peaks), 3),
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f16+fp8 attention" if args.fp8_attention else "f16", "data": "synthetic",
             "config": {"workload": f"SVD img2vid UNet (1.52B params, random init), latent (1,4,{args.frames},"

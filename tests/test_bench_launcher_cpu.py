@@ -1,0 +1,126 @@
+"""`python bench.py --gpus N` without a launcher must start its own N ranks (ref scripts/benchmark_comparison.sh:85-120
+wraps every GPU count in torchrun) from a parent that has imported nothing GPU-related, must relay exactly one JSON
+line, and must never report a smaller job under the name of a larger one."""
+
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(code, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VDPP_SHARE_GPU"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, "-c", textwrap.dedent(code)], cwd=ROOT, env=e, capture_output=True, text=True,
+                          timeout=120)
+
+
+def test_parent_spawns_torchrun_without_importing_torch():
+    r = _run("""
+        import json, subprocess, sys
+        sys.argv = ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"]
+        import bench
+        assert "torch" not in sys.modules, "bench.py imports torch at module level"
+        seen = {}
+        real_popen = subprocess.Popen
+
+        def fake_popen(cmd, env=None, **kw):
+            seen["cmd"], seen["env"] = cmd, env
+            child = ("import json; print('gloo: peer noise on stdout'); print(json.dumps({'not': 'the result'}));"
+                     "print(json.dumps({'metric': 'm', 'value': 1.5, 'n_gpus': 4}))")
+            return real_popen([sys.executable, "-c", child], env=env, **kw)
+
+        subprocess.Popen = fake_popen
+        bench.visible_gpus = lambda: 8
+        try:
+            bench.main()
+        except SystemExit as exc:
+            rc = exc.code
+        assert rc == 0, rc
+        assert "torch" not in sys.modules, "the launching parent imported torch"
+        cmd, env = seen["cmd"], seen["env"]
+        assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd, cmd
+        assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+        assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"], cmd
+        assert env["NCCL_MAX_P2P_NCHANNELS"] == "2" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        assert "RANK" not in env and "WORLD_SIZE" not in env
+    """)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                      # exactly one JSON line on stdout
+    assert json.loads(lines[0]) == {"metric": "m", "value": 1.5, "n_gpus": 4}
+    assert "gloo: peer noise" in r.stderr                 # everything else is passed on as diagnostics
+
+
+def test_parent_refuses_more_ranks_than_devices():
+    r = _run("""
+        import subprocess, sys
+        sys.argv = ["bench.py", "--gpus", "8"]
+        import bench
+        bench.visible_gpus = lambda: 1
+        def boom(*a, **k):
+            raise AssertionError("must not spawn")
+        subprocess.Popen = boom
+        try:
+            bench.main()
+        except SystemExit as exc:
+            assert exc.code not in (0, None), exc.code
+            sys.exit(0)
+        sys.exit(1)
+    """)
+    assert r.returncode == 0, r.stderr
+    assert "--gpus 8 but 1 GPU(s) are visible" in r.stderr and r.stdout.strip() == ""
+
+
+def test_child_failure_is_passed_on_and_no_line_is_printed():
+    r = _run("""
+        import subprocess, sys
+        sys.argv = ["bench.py", "--gpus", "2"]
+        import bench
+        bench.visible_gpus = lambda: 2
+        real_popen = subprocess.Popen
+        subprocess.Popen = lambda cmd, env=None, **kw: real_popen(
+            [sys.executable, "-c", "import sys; print('{\\"metric\\": \\"m\\", \\"value\\": 1}'); sys.exit(3)"], env=env, **kw)
+        try:
+            bench.main()
+        except SystemExit as exc:
+            sys.exit(0 if exc.code == 3 else 1)
+        sys.exit(1)
+    """)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == ""
+
+
+def test_world_size_mismatch_is_an_error_not_a_smaller_run():
+    r = _run("""
+        import sys
+        sys.argv = ["bench.py", "--gpus", "8"]
+        import bench
+        bench.main()
+    """, env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0
+    assert "--gpus 8 but WORLD_SIZE=1" in r.stderr
+
+
+def test_visible_gpus_honours_visible_devices_lists(monkeypatch, tmp_path):
+    sys.path.insert(0, ROOT)
+    import bench
+
+    import glob as globmod
+    nodes = []
+    for i, simd in enumerate((0, 256, 256, 256)):         # node 0 = the CPU
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count 0\nsimd_count {simd}\n")
+        nodes.append(str(d / "properties"))
+    monkeypatch.setattr(globmod, "glob", lambda pat: nodes)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpus() == 2

@@ -282,7 +282,11 @@ def test_groupnorm_large_mean_small_variance(inst, rows, c):
 
 @pytest.mark.parametrize("m,c,n,geglu,route", [(1000, 320, 960, False, 0), (5000, 640, 1920, False, 2), (40000, 320, 2560, True, 3),
                                                (2016, 1280, 3840, False, 0), (3000, 1280, 2560, True, 2), (700, 64, 128, True, 1),
-                                               (33000, 640, 1280, False, 3)])
+                                               (33000, 640, 1280, False, 3),
+                                               # odd row counts: the persistent kernel fetches (mean, rstd) two rows per
+                                               # lane and must not take them (forced route 3 and the automatic choice)
+                                               (40001, 320, 1280, False, 3), (130049, 320, 1280, False, 0),
+                                               (40001, 320, 2560, True, 0)])
 def test_gemm_with_folded_layernorm(m, c, n, geglu, route):
     """LayerNorm folded into the next contraction (sp_ln_stats_f16 + sp_gemm_desc.ln_stats / ln_colsum): the GEMM
     runs on the UN-normalised rows with gamma-scaled weights and applies rstd*(acc - mean*colsum) + (W.beta + b)

@@ -528,9 +528,7 @@ def test_full_width_svd_unet_matches_oracle():
     assert err <= 2e-2, f"full-width UNet rel_l2={err:.3e}"
 
 
-@pytest.mark.parametrize("frames", [14, pytest.param(25, marks=pytest.mark.skipif(
-    __import__("os").environ.get("VDPP_SLOW_TESTS") != "1",
-    reason="80 s of host time: set VDPP_SLOW_TESTS=1 (last run: rel_l2 1.40e-3, DESIGN.md section 4)"))])
+@pytest.mark.parametrize("frames", [14, 25])
 def test_benchmark_shape_unet_forward_matches_oracle(frames):
     """The headline workloads themselves -- the real SVD architecture (1.52 B parameters) on the benchmark latents
     (14 frames = BASELINE configs 2-4, 25 frames = config 5 / SVD-XT; 72 x 128: 129,024 / 230,400 token rows at level

@@ -486,6 +486,13 @@ bool ps_supported(const GemmArgs &a, int bm, int bn) {
   if (a.n_store > 0) return false;
   if (a.ldd % 8 || (a.res1 && a.ldr1 % 8) || (a.res2 && a.ldr2 % 8)) return false;
   if ((int64_t)a.m * a.ldd * 2 >= 0x7fffffff) return false;
+  // residuals are read through 32-bit buffer offsets as well (a column slice of a wider tensor has ldr > ldd)
+  if (a.res1 && (int64_t)a.m * a.ldr1 * 2 >= 0x7fffffff) return false;
+  if (a.res2 && (int64_t)a.m * a.ldr2 * 2 >= 0x7fffffff) return false;
+  // folded LayerNorm: the rows' (mean, rstd) are fetched two rows per lane with the pair clamped to m*8-16; with an
+  // odd m the pair (m-1, m) would be shifted to (m-2, m-1) and row m-1 normalised with its neighbour's statistics.
+  // The ping-pong kernel loads them per row: let it take odd row counts.
+  if (a.ln_stats && (a.m & 1)) return false;
   if (a.bias2 && a.bias2_rows < a.m && a.bias2_rows % bm) return false;   // a tile must not straddle two bias2 rows
   return true;
 }

@@ -22,6 +22,9 @@ from a dedicated side stream:
   sample's first UNet step immediately.
 * recv: ``run_many`` pre-posts the ``irecv`` of sample ``i+1`` (into its own fresh buffer) while
   sample ``i`` computes; the compute stream only waits on the event that marks its own latent as landed.
+  The pre-posted receive is ordered behind the START OF SAMPLE ``i``'s LAST LOCAL STEP, not posted a whole stage
+  ahead: an RCCL receive whose sender is not there yet is a resident kernel spinning on its channels' workgroups,
+  and the persistent GEMM (``csrc/gemm_ps.hip``) wants one 160-KB-LDS workgroup on every CU.
 * ``PipelineConfig.concurrent_samples = S`` (extension): ``run_many`` keeps S samples in flight on S HIP
   streams and issues their UNet steps round-robin, so kernels of independent videos fill each other's idle
   CUs (micro-batched stage).
@@ -125,6 +128,8 @@ class _SideStreamLink:
 
     # -- receive -------------------------------------------------------------------------
     def post_recv(self) -> None:
+        """Enqueue an ``irecv`` on the side stream, ordered behind everything the CURRENT stream holds at this moment
+        (so the call site decides how early the receive kernel may become resident on the GPU)."""
         buf = self.spec.empty()
         buf.record_stream(self.stream)
         allocated = torch.cuda.Event()
@@ -219,8 +224,6 @@ class PipelineStage:
         self._log(f"waiting for latent from rank {upstream}")
         if self._link is not None:
             tensor = self._link.take()
-            if self._more_samples_expected and self._link.posted == 0:
-                self._link.post_recv()
         else:
             tensor = self.config.latent_spec.empty()
             dist.recv(tensor, src=upstream, tag=self.config.send_tag)
@@ -253,7 +256,10 @@ class PipelineStage:
         owned = self._owned_timesteps(sample_idx)
 
         verbose = self.logger.isEnabledFor(logging.INFO)
-        for step in owned:
+        for pos, step in enumerate(owned):
+            if (pos == len(owned) - 1 and self._link is not None and self.config.rank > 0
+                    and self._more_samples_expected and self._link.posted == 0):
+                self._link.post_recv()      # next sample's receive: resident no earlier than this last step
             began = time.time()
             latent = self.model(latent, step)  # the timestep VALUE is the argument (ref :95)
             if verbose:
@@ -316,8 +322,9 @@ class PipelineStage:
         for base in range(0, num_samples, cfg.concurrent_samples):
             group = list(range(base, min(base + cfg.concurrent_samples, num_samples)))
             if not first and self._link is not None:
-                while self._link.posted < len(group):
+                while self._link.posted < len(group):       # first group only; later ones were posted late, below
                     self._link.post_recv()
+            following = min(cfg.concurrent_samples, num_samples - (base + len(group)))
             latents = []
             for j, idx in enumerate(group):
                 st = self._streams[j]
@@ -329,7 +336,12 @@ class PipelineStage:
                         self._more_samples_expected = False
                         latents.append(self._recv_latent())
             owned = [self._owned_timesteps(idx) for idx in group]
-            for k in range(max(len(o) for o in owned)):
+            rounds = max(len(o) for o in owned)
+            for k in range(rounds):
+                if k == rounds - 1 and not first and self._link is not None:
+                    with torch.cuda.stream(self._streams[0]):   # ordered behind lane 0's second-to-last step
+                        for _ in range(following):
+                            self._link.post_recv()
                 for j in range(len(group)):
                     if k < len(owned[j]):
                         with torch.cuda.stream(self._streams[j]):
