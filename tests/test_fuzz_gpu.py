@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
-@pytest.mark.parametrize("route,bm", [(0, 0), (2, 256), (2, 192), (2, 128), (1, 0), (3, 256), (3, 192), (4, 0)])
+@pytest.mark.parametrize("route,bm", [(0, 0), (2, 256), (2, 192), (2, 128), (1, 0), (3, 256), (3, 192), (3, 128), (4, 0)])
 def test_gemm_fuzz(route, bm):
     """route: sp_gemm_set_route (0 automatic, 1 small tiles, 2 ping-pong, 3 persistent-stream, 4 split-K); route 3 draws
     long-K, many-row linear shapes more often so that workgroups walk several tiles, route 4 few-row shapes with

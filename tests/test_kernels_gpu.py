@@ -113,7 +113,11 @@ def test_gemm_large_tile_geglu_conv_temporal(force_large_tiles):
 
 @pytest.mark.parametrize("bm,m,n,k,geglu", [(256, 32256, 2560, 320, True), (192, 32256, 2560, 320, True),
                                             (256, 40000, 1280, 320, False), (192, 129024 // 2, 256, 640, False),
-                                            (192, 50001, 960, 320, False), (192, 36000, 320, 1280, False)])
+                                            (192, 50001, 960, 320, False), (192, 36000, 320, 1280, False),
+                                            # 128 x 320 tiles (4 x 2 waves): every N = 320 k of the two outer levels
+                                            (128, 50001, 960, 320, False), (128, 36000, 320, 1280, False),
+                                            (128, 129024 // 2, 320, 320, False), (128, 33001, 640, 640, False),
+                                            (128, 32256, 1920, 640, False)])
 def test_gemm_persistent_stream_many_tiles(bm, m, n, k, geglu):
     """gemm_ps.hip with several tiles per workgroup (grid 256, up to 6 tiles each): the LDS-DMA stream crosses tile
     boundaries, stores of tile i are in flight behind the loads of tile i+1.  bias + bias2 (one row per batch item),

@@ -124,7 +124,11 @@ float run(const char *src, int hbm, int steps, float *sink, int grid) {
   return ms / 3;
 }
 
-int main() {
+// `dma_probe calib`: the FETCH_SIZE calibration of profiles/r03_fetch_size_calibration.txt -- only the HBM-stream cases
+// on all 256 CUs (every byte is read exactly once from memory: 256 x 240 x 32 KiB = 2,013,265,920 B per dispatch), so
+// that `rocprofv3 --pmc FETCH_SIZE -- tools/dma_probe calib` gives counter-per-known-byte for each access shape.
+int main(int argc, char **argv) {
+  const bool calib = argc > 1 && argv[1][0] == 'c';
   const long total = 3L << 30;                     // 3 GiB source
   char *src; float *sink;
   if (hipMalloc(&src, total) != hipSuccess) { printf("alloc failed\n"); return 1; }
@@ -132,9 +136,9 @@ int main() {
   hipMalloc(&sink, 4096);
   const char *shapes[5] = {"16 rows x  64 B", " 8 rows x 128 B", " 4 rows x 256 B", "1 KiB contiguous", "16 x 64 B, halves paired"};
   const int grids[2] = {256, 32};
-  for (int hbm = 0; hbm < 2; ++hbm) {
+  for (int hbm = calib ? 1 : 0; hbm < 2; ++hbm) {
     const int steps = hbm ? 240 : 2048;
-    for (int gi = 0; gi < 2; ++gi) {
+    for (int gi = 0; gi < (calib ? 1 : 2); ++gi) {
       const int grid = grids[gi];
       for (int path = 0; path < 2; ++path)
         for (int shape = 0; shape < 5; ++shape) {

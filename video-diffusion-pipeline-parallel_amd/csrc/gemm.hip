@@ -492,14 +492,18 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
 
   // ---- persistent-stream tiles (gemm_ps.hip): linear contractions with several tiles per CU, where launch gap,
   // index setup, first-operand latency and the LDS-staged epilogue of a one-tile workgroup are a large share
-  if ((route == 0 || route == 3) && ok256) {
+  if ((route == 0 || route == 3) && (ok256 || ok320)) {
     int bm = 0, bn = 0;
     double best = 0.0;
-    const int cand[2][2] = {{256, 256}, {192, 256}};
-    for (int c = 0; c < 2; ++c) {
+    const int cand[3][2] = {{256, 256}, {192, 256}, {128, 320}};
+    for (int c = 0; c < 3; ++c) {
       const int cbm = cand[c][0], cbn = cand[c][1];
       if ((cbn == 256 && !ok256) || (cbn == 320 && !ok320)) continue;
       if (route == 3 && ((g_route_bm && g_route_bm != cbm) || (g_route_bn && g_route_bn != cbn))) continue;
+      // 128 x 320 tiles: built and verified (round 3), never chosen automatically -- 1.4x the LDS-DMA pieces per FLOP of
+      // a 256-row tile; measured 0-25 % slower than the ping-pong kernel's 256 x 320 tiles on every N = 320 k shape of
+      // the two outer levels
+      if (cbm == 128 && !(route == 3 && g_route_bm == 128)) continue;
       a.tiles_m = (d->m + cbm - 1) / cbm;
       a.tiles_n = d->n / cbn;
       if (!spgemm::ps_supported(a, cbm, cbn)) continue;

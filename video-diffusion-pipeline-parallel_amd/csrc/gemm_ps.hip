@@ -476,10 +476,12 @@ int launch_ps_t(GemmArgs &a, hipStream_t s) {
 }  // namespace
 
 bool ps_supported(const GemmArgs &a, int bm, int bn) {
-  // 256-column tiles only: a 320-column tile needs 4 x 2 waves (10 column sub-tiles per wave) and its residual
-  // prefetch does not fit the register file without spills (measured 0.6x the ping-pong kernel)
-  if (bn != 256) return false;
-  if (bm != 256 && bm != 192) return false;
+  // 256-column tiles of 256 / 192 rows (2 x 4 waves), or 320-column tiles of 128 rows (4 x 2 waves, ten column
+  // sub-tiles of two row sub-tiles per wave: 80 accumulator registers).  A 256 x 320 tile in that arrangement holds 160
+  // accumulator registers and its residual prefetch does not fit the register file without spills (measured 0.6x the
+  // ping-pong kernel in round 2).
+  if (!((bn == 256 && (bm == 256 || bm == 192)) || (bn == 320 && bm == 128))) return false;
+  if (bn == 320 && a.geglu) return false;         // (value, gate) pairs of an odd number of sub-tile pairs
   if (a.n % bn) return false;
   if (a.mode != SP_A_LINEAR) return false;        // the tile loop streams plain rows (nn.Linear / 1x1 convolution)
   if (a.k < 8 * SBK) return false;
@@ -498,7 +500,8 @@ bool ps_supported(const GemmArgs &a, int bm, int bn) {
 }
 
 template <int VAR>
-int launch_ps_v(GemmArgs &a, int bm, hipStream_t s) {
+int launch_ps_v(GemmArgs &a, int bm, int bn, hipStream_t s) {
+  if (bn == 320) return launch_ps_t<128, 320, 4, 2, false, VAR>(a, s);
   if (a.geglu) return bm == 192 ? launch_ps_t<192, 256, 2, 4, true, VAR>(a, s) : launch_ps_t<256, 256, 2, 4, true, VAR>(a, s);
   return bm == 192 ? launch_ps_t<192, 256, 2, 4, false, VAR>(a, s) : launch_ps_t<256, 256, 2, 4, false, VAR>(a, s);
 }
@@ -510,7 +513,7 @@ int launch_ps(GemmArgs &a, int bm, int bn, hipStream_t s) {
 #ifdef SP_GEMM_EXPERIMENTS
   if (a.dbg & 16) pair = false;
 #endif
-  return pair ? launch_ps_v<1>(a, bm, s) : launch_ps_v<0>(a, bm, s);
+  return pair ? launch_ps_v<1>(a, bm, bn, s) : launch_ps_v<0>(a, bm, bn, s);
 }
 
 }  // namespace spgemm

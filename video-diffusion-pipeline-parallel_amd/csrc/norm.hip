@@ -18,7 +18,7 @@ __host__ __device__ inline int gn_rows_per_iter(int oc) { int p = 512 / oc; retu
 __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ part, int64_t rows,
                                 int c, int groups, int splits) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *sh = (float *)smem;                      // [P][C][2]
+  float *sh = (float *)smem;                      // [P][C][2], then [parts][groups][2] behind it
   const int oc = c >> 3;
   const int P = gn_rows_per_iter(oc);
   const int tid = threadIdx.x;
@@ -29,21 +29,26 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
   int64_t r1 = r0 + per; if (r1 > rows) r1 = rows;
   float s[8], ss[8], ref[8];
   const int cpg = c / groups;
+  {
+    // the group's first element of the instance's first row, for each of this thread's 8 channels: one 16-byte load
+    // of the octet that holds it per distinct group (an octet spans at most two groups when cpg >= 8)
+    const f16 *row0 = x + ((int64_t)inst * rows) * c;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    s[e] = ss[e] = 0.f;
-    ref[e] = o < oc ? (float)x[((int64_t)inst * rows) * c + ((o * 8 + e) / cpg) * cpg] : 0.f;
+    for (int e = 0; e < 8; ++e) {
+      s[e] = ss[e] = 0.f;
+      ref[e] = o < oc ? (float)row0[((o * 8 + e) / cpg) * cpg] : 0.f;
+    }
   }
   const f16 *base = x + ((int64_t)inst * rows) * c + o * 8;
   if (pr < P) {
-    // four independent 16-byte loads in flight per thread (memory-level parallelism), then accumulate
+    // eight independent 16-byte loads in flight per thread (memory-level parallelism), then accumulate
     int64_t r = r0 + pr;
-    for (; r + 3 * (int64_t)P < r1; r += 4 * (int64_t)P) {
-      f16x8 v[4];
+    for (; r + 7 * (int64_t)P < r1; r += 8 * (int64_t)P) {
+      f16x8 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *(const f16x8 *)(base + (r + (int64_t)u * P) * c);
+      for (int u = 0; u < 8; ++u) v[u] = *(const f16x8 *)(base + (r + (int64_t)u * P) * c);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e] - ref[e]; s[e] += f; ss[e] += f * f; }
     }
@@ -59,13 +64,28 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
     }
   }
   __syncthreads();
-  if (tid < groups) {
-    float a = 0.f, b = 0.f;
-    for (int q = 0; q < P; ++q)
-      for (int ch = tid * cpg; ch < (tid + 1) * cpg; ++ch) {
+  // fold [P][cpg] values per group in a FIXED order: `parts` threads per group take every parts-th element, then one
+  // thread per group adds the parts in order (deterministic, no atomics)
+  const int parts = (int)blockDim.x / groups;        // >= 1
+  float *sh2 = sh + (size_t)P * c * 2;
+  {
+    const int g = tid % groups, pt = tid / groups;
+    if (pt < parts) {
+      float a = 0.f, b = 0.f;
+      const int n = P * cpg;
+      for (int i = pt; i < n; i += parts) {
+        const int q = i / cpg, ch = g * cpg + (i - q * cpg);
         a += sh[(q * c + ch) * 2 + 0];
         b += sh[(q * c + ch) * 2 + 1];
       }
+      sh2[(pt * groups + g) * 2 + 0] = a;
+      sh2[(pt * groups + g) * 2 + 1] = b;
+    }
+  }
+  __syncthreads();
+  if (tid < groups) {
+    float a = 0.f, b = 0.f;
+    for (int q = 0; q < parts; ++q) { a += sh2[(q * groups + tid) * 2]; b += sh2[(q * groups + tid) * 2 + 1]; }
     float *dst = part + (((int64_t)inst * splits + split) * groups + tid) * 2;
     dst[0] = a; dst[1] = b;
   }
@@ -107,18 +127,56 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const f16 *__restrict
   }
 }
 
+// `part` != null: the block folds the per-split partials of its instance itself (fixed order, fp64: every block of an
+// instance computes bit-identical statistics), so that no finalize launch sits between the two passes; used where an
+// instance has few splits (the per-frame norms), see sp_groupnorm_f16.
 __global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restrict__ stats,
+                                const float *__restrict__ part, int splits, float eps,
                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                 f16 *__restrict__ y, int64_t rows, int c, int groups, int silu,
                                 int64_t rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int oc = c >> 3;
   const int P = gn_rows_per_iter(oc);
   const int tid = threadIdx.x;
   const int inst = blockIdx.x;
-  const int o = tid % oc, pr = tid / oc;
-  if (pr >= P) return;
   const int cpg = c / groups;
   const float *st = stats + (int64_t)inst * groups * 2;
+  if (part) {
+    double *red = (double *)smem;                   // [slices][groups][2]
+    float *stl = (float *)(red + (size_t)((int)blockDim.x / groups) * groups * 2);
+    const int slices = (int)blockDim.x / groups;
+    const int g = tid % groups, sl = tid / groups;
+    if (sl < slices) {
+      const float2 *src = (const float2 *)(part + ((int64_t)inst * splits * groups + g) * 2);
+      double a = 0.0, b = 0.0;
+      int sp = sl;
+      for (; sp + 3 * slices < splits; sp += 4 * slices) {       // four loads in flight
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = src[(int64_t)(sp + u * slices) * groups];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a += v[u].x; b += v[u].y; }
+      }
+      for (; sp < splits; sp += slices) { const float2 v = src[(int64_t)sp * groups]; a += v.x; b += v.y; }
+      red[(sl * groups + g) * 2] = a; red[(sl * groups + g) * 2 + 1] = b;
+    }
+    __syncthreads();
+    if (tid < groups) {
+      double a = 0.0, b = 0.0;
+      for (int q = 0; q < slices; ++q) { a += red[(q * groups + tid) * 2]; b += red[(q * groups + tid) * 2 + 1]; }
+      const double cnt = (double)rows * cpg;
+      const double dmean = a / cnt;
+      double var = b / cnt - dmean * dmean; if (var < 0.0) var = 0.0;
+      const double ref = (double)(float)x[((int64_t)inst * rows) * c + tid * cpg];
+      stl[tid * 2] = (float)(ref + dmean);
+      stl[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    st = stl;
+  }
+  const int o = tid % oc, pr = tid / oc;
+  if (pr >= P) return;
   float sc[8], sf[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -481,7 +539,7 @@ extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *
   SP_REQUIRE(threads <= 1024, "sp_groupnorm_f16: C too large");
   const int splits = gn_splits(instances, rows, P);
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = (size_t)P * c * 2 * sizeof(float);
+  const size_t lds = ((size_t)P * c * 2 + (size_t)(threads / groups) * groups * 2) * sizeof(float);
   SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(gn_stats_kernel, dim3(instances, splits), dim3(threads), lds, s, (const f16 *)x,
                      (float *)ws, rows, c, groups, splits);
@@ -494,11 +552,17 @@ extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *
   blocks_y = (rows + rpb - 1) / rpb;
   SP_CLEAR_STALE_ERROR();
   float *stats = (float *)ws + (size_t)instances * splits * groups * 2;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(instances), dim3(1024), 0, s, (const f16 *)x, (const float *)ws, stats,
-                     rows, c, groups, splits, eps);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(instances, (unsigned)blocks_y), dim3(threads), 0, s,
-                     (const f16 *)x, (const float *)stats, gamma, beta, (f16 *)y, rows, c, groups, fuse_silu,
-                     rpb);
+  // Few splits per instance (the per-frame norms: 74 at 14 frames): every apply block folds its instance's partials in
+  // its prologue (19 KB of L2 reads per block) and the finalize launch between the two passes is gone.  Many splits
+  // (one instance over all frames: 512 x 32 partials = 131 KB per apply block) keep the one-block-per-instance fold.
+  const bool fold_in_apply = splits <= 128;
+  if (!fold_in_apply)
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(instances), dim3(1024), 0, s, (const f16 *)x, (const float *)ws, stats,
+                       rows, c, groups, splits, eps);
+  const size_t lds_apply = fold_in_apply ? (size_t)(threads / groups) * groups * 2 * sizeof(double) + groups * 2 * sizeof(float) : 0;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(instances, (unsigned)blocks_y), dim3(threads), lds_apply, s,
+                     (const f16 *)x, (const float *)stats, fold_in_apply ? (const float *)ws : (const float *)nullptr, splits,
+                     eps, gamma, beta, (f16 *)y, rows, c, groups, fuse_silu, rpb);
   SP_CHECK_LAUNCH("sp_groupnorm_f16(apply)");
   return SP_OK;
 }
