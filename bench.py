@@ -121,6 +121,8 @@ def parse():
     ap.add_argument("--fp8-attention", action="store_true",
                     help="spatial self-attention on fp8-e4m3 MFMA (BASELINE config 5; use with --frames 25 --total-steps 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true",
+                    help="skip the temporal-VAE decode timing (reported beside the headline metric, never inside it)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
     return ap.parse_args()
@@ -233,6 +235,60 @@ def cpu_simulator():
     out["c_oracle"] = {"workload": "DummyUNet(8,16) (1,8,8,32,32) fp32, 8 steps (oracle/dummy_unet_ref.c, scalar)",
                        "threads": 1, "samples_per_s": 1.0 / (time.perf_counter() - t0)}
     return out
+
+
+def vae_decode_leg(device, frames, h, w):
+    """Temporal VAE decoder (random weights of the SVD architecture) on one synthetic latent video: ms per video."""
+    from vdpp_amd.models.vae_hip import TemporalDecoderHIP, VAEDecoderConfig, param_count, random_state_dict
+
+    cfg = VAEDecoderConfig.svd()
+    dec = TemporalDecoderHIP(cfg, random_state_dict(cfg, seed=0), device)
+    gen = torch.Generator(device=device).manual_seed(7)
+    lat = (torch.randn((1, 4, frames, h, w), generator=gen, device=device) * cfg.scaling_factor).half()
+    chunk = 14                                           # the reference's decode_chunk_size
+    with torch.no_grad():
+        dec.decode_latents(lat, frames, decode_chunk_size=chunk)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        e0.record()
+        for _ in range(reps):
+            vid = dec.decode_latents(lat, frames, decode_chunk_size=chunk)
+        e1.record()
+        torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / reps
+    # multiply-add FLOPs of the decoder calls (same model as oracle/vae_temporal_decoder_ref.py::decoder_flops)
+    fl = 0.0
+    for i in range(0, frames, chunk):
+        fl += _vae_flops(cfg, min(chunk, frames - i), h, w)
+    res = {"decode_ms": ms, "tflop": fl / 1e12, "achieved_tflops": fl / 1e9 / ms, "frac_of_fp16_peak": fl / 1e9 / ms / PEAK_FP16_TFLOPS,
+           "output": list(vid.shape), "output_dtype": "fp32", "decode_chunk_size": chunk, "params": param_count(cfg),
+           "peak_memory_gb": round(torch.cuda.max_memory_allocated(device) / 2**30, 2),
+           "note": "AutoencoderKLTemporalDecoder restated (random init, fp16 storage / fp32 accumulate); NOT part of "
+                   "`value`: the benchmark's videos end as latents, like the reference benchmark's"}
+    del dec, vid
+    torch.cuda.empty_cache()
+    return res
+
+
+def _vae_flops(cfg, frames, h, w):
+    ch = list(cfg.block_out_channels)
+    px = frames * h * w
+
+    def res(cin, cout, px):
+        return 2.0 * px * (9 * cin * cout + 9 * cout * cout + 2 * 3 * cout * cout + (cin * cout if cin != cout else 0))
+
+    c = ch[-1]
+    tot = 2.0 * px * 9 * cfg.latent_channels * c + 2 * res(c, c, px) + 4 * 2.0 * px * c * c + 2 * 2.0 * frames * (h * w) ** 2 * c
+    prev = c
+    for i, co in enumerate(reversed(ch)):
+        for j in range(cfg.layers_per_block + 1):
+            tot += res(prev if j == 0 else co, co, px)
+        if i != len(ch) - 1:
+            px *= 4
+            tot += 2.0 * px * 9 * co * co
+        prev = co
+    return tot + 2.0 * px * 9 * ch[0] * cfg.out_channels + 2.0 * px * 3 * cfg.out_channels ** 2
 
 
 def visible_gpus():
@@ -536,14 +592,16 @@ def main():
                 model(lat, 0)
                 torch.cuda.synchronize(device)
             prof, ops.PROFILE = ops.PROFILE, None
-        by, shapes = {}, {}
+        by, shapes, templates = {}, {}, {}
         for kind, fl, e0, e1, nb, tag in prof:
             sec = e0.elapsed_time(e1) / 1e3
             acc = by.setdefault(kind, [0.0, 0.0, 0, 0.0])
             acc[0] += fl; acc[1] += sec; acc[2] += 1; acc[3] += nb
             if kind == "gemm":
-                sh = shapes.setdefault(tag, [0.0, 0.0, 0])
+                sh = shapes.setdefault(tag[:5], [0.0, 0.0, 0, tag[5]])
                 sh[0] += fl; sh[1] += sec; sh[2] += 1
+                tp = templates.setdefault(tag[5], [0.0, 0.0, 0])      # kernel instantiation that took the launch
+                tp[0] += fl; tp[1] += sec; tp[2] += 1
         gf, gt, gn, gb = by["gemm"]
         # HBM/fabric bytes per launch come from PMC passes (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE) that
         # cannot run inside this process; they are collected with tools/pmc_forward.sh on a named commit and committed.
@@ -569,14 +627,23 @@ def main():
                            "flop_per_launch_avg": gf / gn,
                            # the ten shapes with the most time: [rows, columns, channels per tap, gather mode, GEGLU]
                            "top_shapes": [{"shape": list(k), "launches": v[2], "ms": round(1e3 * v[1], 3),
-                                           "tflops": round(v[0] / v[1] / 1e12, 1)}
-                                          for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:10]]}
+                                           "tflops": round(v[0] / v[1] / 1e12, 1), "kernel": v[3]}
+                                          for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:10]],
+                           # FLOPs per kernel instantiation of one forward (names as rocprofv3 prints them): with
+                           # profiles/*_kernel_stats.csv the fraction of peak per template can be recomputed
+                           "per_template": [{"kernel": k, "launches": v[2], "tflop": round(v[0] / 1e12, 4),
+                                             "ms": round(1e3 * v[1], 3), "tflops": round(v[0] / v[1] / 1e12, 1)}
+                                            for k, v in sorted(templates.items(), key=lambda kv: -kv[1][1])]}
         if "attn_spatial" in by:
             af, at, an, _ = by["attn_spatial"]
             out["roofline_attention"] = {"bound": "mfma", "kernel": "attn_spatial_kernel",
                                          "achieved": af / at / 1e12, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                                          "frac": af / at / 1e12 / PEAK_FP16_TFLOPS, "launches_per_forward": an,
                                          "avg_launch_us": 1e6 * at / an}
+    # ---- what the last stage would add per video if it also decoded (ref scripts/generate_video_demo.py:
+    # 154-195: decode_latents, decode_chunk_size 14).  Outside the headline metric: the benchmark's videos are latents.
+    if rank == 0 and not args.no_decode:
+        out["vae_decode"] = vae_decode_leg(device, args.frames, args.height, args.width)
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
         del model, stage
         torch.cuda.empty_cache()

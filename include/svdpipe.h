@@ -105,6 +105,10 @@ int sp_gemm_f16(const sp_gemm_desc *desc, void *stream);
 /* bytes of sp_gemm_desc.workspace this contraction can use (0: it is not a split-K candidate) */
 size_t sp_gemm_workspace_bytes(const sp_gemm_desc *desc);
 
+/* Name of the kernel instantiation the calling thread's last sp_gemm_f16 launched (e.g. "gemm_pp_kernel<256, 320, 0>";
+ * thread-local, valid until that thread's next call): lets a profile attribute FLOPs to kernel templates. */
+const char *sp_gemm_last_kernel(void);
+
 /* Test / micro-benchmark hook (no counterpart in the reference): pins the kernel family sp_gemm_f16 picks for the
  * shapes that family supports; everything else keeps the automatic choice.  Process-wide, not thread-safe: set it
  * before the calls it should affect.  route 0 = automatic (default), 1 = small tiles only, 2 = ping-pong large tiles
@@ -199,6 +203,31 @@ int sp_concat_channels_f16(const void *a, int ca, const void *b, int cb, void *o
                            void *stream);
 /* y = x + vec[c] broadcast over rows (used for the degenerate single-token cross-attention) */
 int sp_add_rowvec_f16(const void *x, const float *vec, void *y, int64_t rows, int c, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Temporal VAE decoder on the last stage: /root/reference/scripts/generate_video_demo.py:154-195
+ * calls diffusers AutoencoderKLTemporalDecoder.decode; its convolutions, GroupNorms and projections are the kernels
+ * above, the two below are what it needs besides.
+ * ------------------------------------------------------------------------------------------- */
+/* in-place softmax over each of `rows` rows of x (fp16 [rows][ld], `cols` <= 16384 columns, multiple of 8): the
+ * [tokens][tokens] scores of the mid block's single-head attention (attention_processor.py Attention, heads = 1,
+ * dim_head = 512), which sp_gemm_f16 wrote already scaled by 1/sqrt(dim_head).  fp32 statistics. */
+int sp_softmax_rows_f16(void *x, int64_t ld, int64_t rows, int cols, void *stream);
+/* Both ends of one decoder call work on `n` consecutive entries g = flat0 .. flat0+n-1 of the flattened (batch, frame)
+ * list of a video tensor with F frames per batch item (generate_video_demo.py:162-181 cuts that flat list into chunks
+ * of decode_chunk_size); entry g is batch item g / F, frame g % F, and element (g, channel c, pixel p) of the tensor
+ * sits at  base + (g/F)*sb + c*sc + (g%F)*sf + p  (element strides: (B,C,F,H,W) has sb = C*F*hw, sc = F*hw, sf = hw;
+ * (B*F,C,H,W) has sb = F*C*hw, sc = hw, sf = C*hw).
+ * pack: latent channels 0-3 * scale (= 1/scaling_factor) -> channels-last rows [n*h*w][cpad], other channels zero. */
+int sp_vae_pack_latent_f16(const void *latent, void *rows, float scale, int64_t flat0, int n, int F, int64_t sb,
+                           int64_t sc, int64_t sf, int h, int w, int cpad, void *stream);
+/* frames out: time_conv_out = Conv3d(3 -> 3, kernel (3,1,1), zero padding over the `frames` of each of the call's
+ * `batch` items, n = batch*frames) applied to the channels-last rows conv_out produced (fp16 [n*h*w][ld], channels
+ * 0-2), written into the video tensor `out` (fp16, or fp32 when out_fp32 != 0) at the strides above.
+ * weight: fp32 [3][3][3] = [out][in][tap], bias fp32 [3]. */
+int sp_vae_frames_out_f16(const void *rows, int64_t ld, const float *weight, const float *bias, void *out,
+                          int out_fp32, int batch, int frames, int h, int w, int64_t flat0, int F, int64_t sb,
+                          int64_t sc, int64_t sf, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DummyUNet (simulator-path model, /root/reference/src/models/dummy_unet.py:37-59), fp32 NCDHW:

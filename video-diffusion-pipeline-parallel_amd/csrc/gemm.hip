@@ -388,6 +388,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_f16_kernel(const GemmArgs
 
 template <int BM, int BN, int WM, int WN, int STAGES>
 int launch(GemmArgs &a, hipStream_t s) {
+  spgemm::note_kernel("gemm_f16_kernel<%d, %d, %d, %d, %d>", BM, BN, WM, WN, STAGES);
   constexpr size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
   static_assert((size_t)BM * (BN + 8) * 2 <= lds, "epilogue staging tile must fit in the ring");
   static bool attr_set[SP_MAX_DEVICES] = {};
@@ -567,6 +568,18 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
 }
 
 }  // namespace
+
+namespace spgemm {
+static thread_local char g_last_kernel[96] = "";
+void note_kernel(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+  va_end(ap);
+}
+}  // namespace spgemm
+
+extern "C" const char *sp_gemm_last_kernel(void) { return spgemm::g_last_kernel; }
 
 extern "C" size_t sp_gemm_workspace_bytes(const sp_gemm_desc *d) {
   if (!d || d->m <= 0 || d->n <= 0 || d->cin <= 0) return 0;

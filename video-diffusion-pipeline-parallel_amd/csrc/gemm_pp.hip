@@ -610,6 +610,7 @@ int launch_pp(GemmArgs &a, hipStream_t s) {
     return rc;
   a.tiles_m = (a.m + BM - 1) / BM;
   a.tiles_n = a.n / BN;
+  note_kernel((EXP & 128) ? "gemm_pp_kernel<%d, %d, %d> + splitk_reduce_kernel" : "gemm_pp_kernel<%d, %d, %d>", BM, BN, EXP);
   SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, EXP>), dim3(a.tiles_m * a.tiles_n * ((EXP & 128) ? a.ksplit : 1)),
                      dim3(BM == 128 ? 256 : 512), lds, s, a);

@@ -467,6 +467,7 @@ int launch_ps_t(GemmArgs &a, hipStream_t s) {
   a.tiles_n = a.n / BN;
   const int ntiles = a.tiles_m * a.tiles_n;
   const int grid = ntiles < 256 ? ntiles : 256;       // one workgroup per CU
+  note_kernel("gemm_ps_kernel<%d, %d, %d, %d, %s, %d>", BM, BN, WM, WN, GEGLU ? "true" : "false", VAR);
   SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WM, WN, GEGLU, VAR>), dim3(grid), dim3(512), lds, s, a);
   SP_CHECK_LAUNCH("sp_gemm_f16(ps)");

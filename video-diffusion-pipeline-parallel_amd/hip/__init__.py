@@ -47,6 +47,7 @@ SIGNATURES = {
     "sp_gemm_f16": (_I, [ctypes.POINTER(GemmDesc), _P]),
     "sp_gemm_workspace_bytes": (_Z, [ctypes.POINTER(GemmDesc)]),
     "sp_gemm_set_route": (_I, [_I, _I, _I]),
+    "sp_gemm_last_kernel": (ctypes.c_char_p, []),
     "sp_gemv_f16": (_I, [_P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "sp_gemv_batched_f16": (_I, [_P, _L, _L, _P, _L, _P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P]),
     "sp_sinusoid_f16": (_I, [_P, _P, _I, _I, _P]),
@@ -62,6 +63,9 @@ SIGNATURES = {
     "sp_euler_step_f16": (_I, [_P, _P, _P, _L, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
     "sp_concat_channels_f16": (_I, [_P, _I, _P, _I, _P, _L, _P]),
     "sp_add_rowvec_f16": (_I, [_P, _P, _P, _L, _I, _P]),
+    "sp_softmax_rows_f16": (_I, [_P, _L, _L, _I, _P]),
+    "sp_vae_pack_latent_f16": (_I, [_P, _P, _F, _L, _I, _I, _L, _L, _L, _I, _I, _I, _P]),
+    "sp_vae_frames_out_f16": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _L, _L, _P]),
     "sp_dummy_unet_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _F, _I, _I, _I, _I, _I, _I, _P]),
 }
 

@@ -114,8 +114,10 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
     # algorithmic bytes of this launch: every operand element once (A without tap re-reads), output and residuals once
     a_rows = d.n_img * d.hin * d.win if mode == A_CONV3X3 else m
     nbytes = 2.0 * (a_rows * cin + n * taps * cin + m * (n_store or nout) * (1 + (res1 is not None) + (res2 is not None)))
-    with _Timed("gemm", 2.0 * m * n * taps * cin, nbytes, (m, n, cin, mode, bool(geglu))):
+    with _Timed("gemm", 2.0 * m * n * taps * cin, nbytes, (m, n, cin, mode, bool(geglu))) as tm:
         _check(load().sp_gemm_f16(ctypes.byref(d), _stream()), "sp_gemm_f16")
+        if PROFILE is not None:      # which kernel template took it (per-template FLOPs in the profile summary)
+            tm.tag = tm.tag + (load().sp_gemm_last_kernel().decode(),)
     return out
 
 
@@ -227,6 +229,41 @@ def attn_temporal(q, k, v, o, *, ldq, ldk, ldv, ldo, batch, frames, hw, heads, s
 def pack_input(latent, image_latents, out, *, in_scale, b, frames, h, w, cpad):
     _check(load().sp_pack_input_f16(_f16(latent, "latent").data_ptr(), _f16(image_latents, "image_latents").data_ptr(),
                                     out.data_ptr(), in_scale, b, frames, h, w, cpad, _stream()), "sp_pack_input_f16")
+    return out
+
+
+def softmax_rows(x, *, rows, cols, ld=None):
+    """In-place softmax of every row of the fp16 matrix ``x`` (the VAE mid block's attention scores)."""
+    ld = int(ld if ld is not None else cols)
+    with _Timed("softmax_rows", 0.0, 2 * 2.0 * rows * cols):
+        _check(load().sp_softmax_rows_f16(_rows(x, "x", ld).data_ptr(), ld, rows, cols, _stream()), "sp_softmax_rows_f16")
+    return x
+
+
+def video_strides(t, layout):
+    """(sb, sc, sf) element strides of a contiguous video tensor: "bcfhw" = (B,C,F,H,W), "nchw" = (B*F,C,H,W)."""
+    if layout == "bcfhw":
+        _, c, f, h, w = t.shape
+        return c * f * h * w, f * h * w, h * w
+    _, c, h, w = t.shape
+    return None, h * w, c * h * w          # sb = F*C*hw depends on the caller's frames per batch item
+
+
+def vae_pack_latent(latent, rows, *, scale, flat0, n, frames_per_item, strides, h, w, cpad):
+    sb, sc, sf = strides
+    _check(load().sp_vae_pack_latent_f16(_f16(latent, "latent").data_ptr(), _f16(rows, "rows").data_ptr(), scale, flat0, n,
+                                         frames_per_item, sb, sc, sf, h, w, cpad, _stream()), "sp_vae_pack_latent_f16")
+    return rows
+
+
+def vae_frames_out(rows, weight, bias, out, *, batch, frames, h, w, flat0, frames_per_item, strides):
+    sb, sc, sf = strides
+    if out.dtype not in (torch.float16, torch.float32) or not out.is_contiguous():
+        raise TypeError("vae_frames_out: out must be a contiguous float16 or float32 tensor")
+    with _Timed("vae_frames_out", 0.0, 2.0 * batch * frames * h * w * (rows.shape[1] + 3)):
+        _check(load().sp_vae_frames_out_f16(_f16(rows, "rows").data_ptr(), rows.shape[1], weight.data_ptr(), bias.data_ptr(),
+                                            out.data_ptr(), int(out.dtype == torch.float32), batch, frames, h, w, flat0,
+                                            frames_per_item, sb, sc, sf, _stream()), "sp_vae_frames_out_f16")
     return out
 
 
