@@ -476,6 +476,26 @@ def test_attention_spatial_online_softmax_rescale(seq):
     check(o, ref, l2=3e-3, mx=2e-2)
 
 
+@pytest.mark.parametrize("batch,seq,heads", [(2, 4608, 2), (1, 9216, 1), (3, 4096, 1)])
+def test_attention_spatial_long_rows(batch, seq, heads):
+    """Rows of 4,096-9,216 tokens (the benchmark's level 0 is 9,216): 64-144 K/V tiles per query block, with late
+    dominant keys so that the deferred-rescale branch runs far into the row; same tolerance as the short rows."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(seq + heads)
+    c = heads * 64
+    qkv = h(torch.randn(batch * seq, 3 * c, generator=g))
+    for i, (qrow, krow, amp) in enumerate([(5, seq - 50, 3.0), (77, 130, 2.0), (300, seq // 2, 2.5), (40, 3000, 3.0),
+                                           (100, 1000, 2.5), (470, 2000, 2.0)]):
+        qkv[krow, c:c + 64] = h(qkv[qrow, :64] * amp)          # head 0 of batch item 0
+    d = qkv.half().to(DEV)
+    o = torch.empty(batch * seq, c, dtype=torch.float16, device=DEV)
+    ops.attn_spatial(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=batch,
+                     seq=seq, heads=heads)
+    q, k, v = [t.reshape(batch, seq, heads, 64).transpose(1, 2) for t in qkv.split(c, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(batch * seq, c)
+    check(o, ref, l2=3e-3, mx=2e-2)
+
+
 def _e4m3(t):
     """round-trip through OCP e4m3fn (what the fp8 path's quantiser stores), as fp32"""
     return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
