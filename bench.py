@@ -122,7 +122,8 @@ def parse():
                     help="spatial self-attention on fp8-e4m3 MFMA (BASELINE config 5; use with --frames 25 --total-steps 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true",
-                    help="skip the temporal-VAE decode timing (reported beside the headline metric, never inside it)")
+                    help="skip the edge-stage timings (temporal-VAE decode, CLIP / VAE image encode; reported beside the "
+                         "headline metric, never inside it)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
     return ap.parse_args()
@@ -267,6 +268,63 @@ def vae_decode_leg(device, frames, h, w):
            "note": "AutoencoderKLTemporalDecoder restated (random init, fp16 storage / fp32 accumulate); NOT part of "
                    "`value`: the benchmark's videos end as latents, like the reference benchmark's"}
     del dec, vid
+    torch.cuda.empty_cache()
+    return res
+
+
+def image_encode_leg(device, frames, h, w):
+    """First stage's encode_image (ref scripts/generate_video_demo.py:92-151): CLIP ViT-H/14 image embeddings and the
+    VAE encoder's image latents, random weights of the SVD architectures; ms per video (once per video, not per step)."""
+    from vdpp_amd.models.clip_hip import CLIPVisionHIP, CLIPVisionSpec
+    from vdpp_amd.models.vae_hip import ImageEncoderHIP, VAEDecoderConfig, random_encoder_state_dict
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1) / reps
+
+    gen = torch.Generator(device=device).manual_seed(11)
+    spec = CLIPVisionSpec.svd()
+    c, L, I = spec.hidden_size, spec.num_hidden_layers, spec.intermediate_size
+    sd = {}
+
+    def rnd(*shape, std):
+        return (torch.randn(shape, generator=gen, device=device) * std).half()
+
+    sd["vision_model.embeddings.class_embedding"] = rnd(c, std=0.02)
+    sd["vision_model.embeddings.patch_embedding.weight"] = rnd(c, 3, spec.patch_size, spec.patch_size, std=0.02)
+    sd["vision_model.embeddings.position_embedding.weight"] = rnd((spec.image_size // spec.patch_size) ** 2 + 1, c, std=0.02)
+    for n in ("pre_layrnorm", "post_layernorm"):
+        sd[f"vision_model.{n}.weight"], sd[f"vision_model.{n}.bias"] = torch.ones(c).half(), torch.zeros(c).half()
+    for i in range(L):
+        p = f"vision_model.encoder.layers.{i}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[f"{p}.self_attn.{n}.weight"], sd[f"{p}.self_attn.{n}.bias"] = rnd(c, c, std=0.02), torch.zeros(c).half()
+        for n in ("layer_norm1", "layer_norm2"):
+            sd[f"{p}.{n}.weight"], sd[f"{p}.{n}.bias"] = torch.ones(c).half(), torch.zeros(c).half()
+        sd[f"{p}.mlp.fc1.weight"], sd[f"{p}.mlp.fc1.bias"] = rnd(I, c, std=0.02), torch.zeros(I).half()
+        sd[f"{p}.mlp.fc2.weight"], sd[f"{p}.mlp.fc2.bias"] = rnd(c, I, std=0.02), torch.zeros(c).half()
+    sd["visual_projection.weight"] = rnd(spec.projection_dim, c, std=0.02)
+    clip = CLIPVisionHIP(spec, sd, device)
+    del sd
+    px = torch.randn((1, 3, spec.image_size, spec.image_size), generator=gen, device=device).half()
+    cfg = VAEDecoderConfig.svd()
+    enc = ImageEncoderHIP(cfg, random_encoder_state_dict(cfg, seed=0), device)
+    img = torch.randn((1, 3, 8 * h, 8 * w), generator=gen, device=device).clamp(-1, 1).half()
+    with torch.no_grad():
+        clip_ms = timed(lambda: clip(px))
+        enc_ms = timed(lambda: enc.encode_image_latents(img, frames))
+    res = {"clip_image_embeddings_ms": clip_ms, "vae_image_latents_ms": enc_ms,
+           "image": [1, 3, 8 * h, 8 * w], "clip_pixel_values": [1, 3, spec.image_size, spec.image_size],
+           "note": "CLIPVisionModelWithProjection (ViT-H/14) and the AutoencoderKLTemporalDecoder encoder, random init; once "
+                   "per video on the first stage, NOT part of `value`"}
+    del clip, enc
     torch.cuda.empty_cache()
     return res
 
@@ -644,6 +702,7 @@ def main():
     # 154-195: decode_latents, decode_chunk_size 14).  Outside the headline metric: the benchmark's videos are latents.
     if rank == 0 and not args.no_decode:
         out["vae_decode"] = vae_decode_leg(device, args.frames, args.height, args.width)
+        out["image_encode"] = image_encode_leg(device, args.frames, args.height, args.width)
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
         del model, stage
         torch.cuda.empty_cache()

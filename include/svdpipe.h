@@ -229,6 +229,33 @@ int sp_vae_frames_out_f16(const void *rows, int64_t ld, const float *weight, con
                           int out_fp32, int batch, int frames, int h, int w, int64_t flat0, int F, int64_t sb,
                           int64_t sc, int64_t sf, void *stream);
 
+/* Encoder half (vae.encode(image).latent_dist.mode(), generate_video_demo.py:139-148).  flip != 0 mirrors the image in
+ * both axes between the tensor and the rows (pixel (y,x) <-> row (H-1-y)*W + (W-1-x)): the engine runs the encoder on
+ * the mirrored image, where Downsample2D's bottom/right padding is the stride-2 kernel's top/left padding.
+ * pack: image fp16 (batch,3,h,w) -> channels-last rows [batch*h*w][cpad] (channels 3.. zero). */
+int sp_vae_image_pack_f16(const void *image, void *rows, int batch, int h, int w, int cpad, int flip, void *stream);
+/* latent out: rows fp16 [batch*h*w][ld], channels 0..channels-1 -> out fp16 (batch, channels, frames, h, w), every frame
+ * a copy (image_latents.unsqueeze(2).repeat(1,1,num_frames,1,1), generate_video_demo.py:148). */
+int sp_vae_latent_out_f16(const void *rows, int64_t ld, void *out, int batch, int channels, int frames, int h, int w,
+                          int flip, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CLIP image encoder on the first stage: /root/reference/scripts/generate_video_demo.py:108-112 calls
+ * transformers CLIPVisionModelWithProjection (ViT-H/14); its contractions and LayerNorms are the kernels above.
+ * ------------------------------------------------------------------------------------------- */
+/* im2col of non-overlapping patches: pixels fp16 (batch,3,h,w) -> rows fp16 [batch*(h/patch)*(w/patch)][kpad],
+ * k = c*patch*patch + ky*patch + kx (= the flattened Conv2d weight of CLIPVisionEmbeddings.patch_embedding), zeros
+ * from 3*patch*patch up to kpad. */
+int sp_patchify_f16(const void *pixels, void *rows, int batch, int h, int w, int patch, int kpad, void *stream);
+/* softmax(q k^T * scale) v for short sequences (seq <= 512) and any head width that is a multiple of 8 up to 128
+ * (ViT-H: 257 tokens, 16 heads of 80): row (b*seq + i), head hh of q/k/v/o starts at column hh*head_dim.  fp32 math,
+ * fp16 in/out; K and V of one (batch item, head) must fit in LDS. */
+int sp_attn_small_f16(const void *q, const void *k, const void *v, void *o, int64_t ldq, int64_t ldk, int64_t ldv,
+                      int64_t ldo, int batch, int seq, int heads, int head_dim, float scale, void *stream);
+/* y = gelu(x) elementwise over n fp16 values (n a multiple of 8): exact erf form (hidden_act "gelu"), or
+ * x*sigmoid(1.702 x) when quick != 0 ("quick_gelu"). */
+int sp_gelu_f16(const void *x, void *y, int64_t n, int quick, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * DummyUNet (simulator-path model, /root/reference/src/models/dummy_unet.py:37-59), fp32 NCDHW:
  * out = x + gain*Conv3d(SiLU(Conv3d(x))) + LayerNorm_C(x).  hidden: scratch [B][hidden][F][H][W].

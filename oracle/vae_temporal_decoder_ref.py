@@ -32,6 +32,14 @@ What this restatement ASSUMES about diffusers 0.36 (each is a place where a pinn
      decodes ``decode_chunk_size=14`` frames per call), zero padding in time.
  (6) ``decode_latents`` divides by ``scaling_factor`` first and returns ``(B, 3, F, 8H, 8W)`` in fp32.
 
+The ENCODER half (``vae.encode(image).latent_dist.mode()``, ref ``generate_video_demo.py:117-145``) is restated at the
+bottom of this file (``EncoderRef`` / ``encode_image_latents``) under the same status; its assumptions:
+ (7) ``Encoder``: ``conv_in`` 3x3 -> four DownEncoderBlock2D of two ResnetBlock2D (eps 1e-6, no time embedding, 1x1
+     shortcut when the widths differ), the first three followed by Downsample2D(padding=0): ``F.pad(x, (0,1,0,1))`` then
+     a stride-2 3x3 convolution WITHOUT padding -> UNetMidBlock2D (resnet, the same single-head attention as (4),
+     resnet) -> GroupNorm(32, eps 1e-6) + SiLU -> ``conv_out`` to ``2*latent_channels``; then ``quant_conv`` 1x1.
+ (8) ``latent_dist.mode()`` is the mean = the first ``latent_channels`` of those; NO ``scaling_factor`` on this path.
+
 Only ``tests/`` and ``bench.py``'s optional decode check import this.
 """
 
@@ -252,3 +260,77 @@ def decoder_flops(cfg: VAEDecoderConfig, frames: int, h: int, w: int) -> float:
         prev = co
     total += 2.0 * px * 9 * ch[0] * cfg.out_channels + 2.0 * px * 3 * cfg.out_channels ** 2
     return total
+
+
+# ------------------------------------------------------------------------------------------------ encoder half
+class _Downsample(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1)))
+
+
+class _Down(nn.Module):
+    def __init__(self, cin, cout, layers, downsample, groups):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Res2D(cin if i == 0 else cout, cout, 1e-6, groups) for i in range(layers)])
+        self.downsamplers = nn.ModuleList([_Downsample(cout)]) if downsample else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+        return x
+
+
+class _Mid2D(nn.Module):
+    def __init__(self, c, groups):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Res2D(c, c, 1e-6, groups), _Res2D(c, c, 1e-6, groups)])
+        self.attentions = nn.ModuleList([_Attention(c, groups)])
+
+    def forward(self, x):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x)))
+
+
+class EncoderRef(nn.Module):
+    """``AutoencoderKLTemporalDecoder.encoder`` + ``.quant_conv`` (load the checkpoint's ``encoder.*`` entries under
+    ``encoder.`` and ``quant_conv.*`` as they are)."""
+
+    def __init__(self, cfg: VAEDecoderConfig, in_channels: int = 3):
+        super().__init__()
+        self.cfg = cfg
+        ch = list(cfg.block_out_channels)
+        g = cfg.norm_groups
+        enc = nn.Module()
+        enc.conv_in = nn.Conv2d(in_channels, ch[0], 3, padding=1)
+        downs, prev = [], ch[0]
+        for i, c in enumerate(ch):
+            downs.append(_Down(prev, c, cfg.layers_per_block, i != len(ch) - 1, g))
+            prev = c
+        enc.down_blocks = nn.ModuleList(downs)
+        enc.mid_block = _Mid2D(ch[-1], g)
+        enc.conv_norm_out = nn.GroupNorm(g, ch[-1], eps=1e-6)
+        enc.conv_out = nn.Conv2d(ch[-1], 2 * cfg.latent_channels, 3, padding=1)
+        self.encoder = enc
+        self.quant_conv = nn.Conv2d(2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
+
+    def forward(self, x):                       # (B, 3, H, W) -> moments (B, 2*latent, H/8, W/8)
+        e = self.encoder
+        x = e.conv_in(x)
+        for d in e.down_blocks:
+            x = d(x)
+        x = e.mid_block(x)
+        x = e.conv_out(F.silu(e.conv_norm_out(x)))
+        return self.quant_conv(x)
+
+
+def encode_image_latents(image, encoder: EncoderRef, num_frames: int):
+    """``/root/reference/scripts/generate_video_demo.py:139-148``: ``vae.encode(image).latent_dist.mode()`` (the mean,
+    no scaling factor) repeated over the frames: (B, 3, H, W) -> (B, latent, F, H/8, W/8)."""
+    with torch.no_grad():
+        mean = encoder(image)[:, :encoder.cfg.latent_channels]
+    return mean.unsqueeze(2).repeat(1, 1, num_frames, 1, 1)

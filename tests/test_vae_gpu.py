@@ -165,3 +165,49 @@ def test_decoder_benchmark_shape_matches_oracle():
         want = ref(z.float(), 14)
     err = rel_l2(got.float().cpu(), want)
     assert torch.isfinite(got).all() and err <= 2e-2, f"benchmark-shape decoder rel_l2={err:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ encoder half
+def _enc_pair(cfg_name, seed):
+    from oracle.vae_temporal_decoder_ref import EncoderRef
+    from oracle.vae_temporal_decoder_ref import VAEDecoderConfig as RefCfg
+    from vdpp_amd.models.vae_hip import ImageEncoderHIP, VAEDecoderConfig, random_encoder_state_dict
+
+    cfg = VAEDecoderConfig.tiny(64) if cfg_name == "tiny" else VAEDecoderConfig.svd()
+    rcfg = RefCfg.tiny(64) if cfg_name == "tiny" else RefCfg.svd()
+    sd = random_encoder_state_dict(cfg, seed=seed)
+    hip = ImageEncoderHIP(cfg, sd, DEV)
+    ref = EncoderRef(rcfg).eval()
+    ref.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    return hip, ref
+
+
+def test_encoder_boundary_kernels_mirror_round_trip():
+    """pack with the mirror, unpack with the mirror: the identity (the encoder engine runs on the mirrored image)."""
+    ops = _ops()
+    img = torch.randn(2, 3, 6, 10, generator=torch.Generator().manual_seed(4)).half()
+    for flip in (False, True):
+        rows = torch.full((2 * 60, 64), 3.0, dtype=torch.float16, device=DEV)
+        ops.vae_image_pack(img.to(DEV), rows, batch=2, h=6, w=10, cpad=64, flip=flip)
+        want = img.flip(-1, -2) if flip else img
+        assert torch.equal(rows[:, :3].cpu(), want.permute(0, 2, 3, 1).reshape(120, 3)) and float(rows[:, 3:].abs().max()) == 0
+        out = torch.zeros(2, 3, 4, 6, 10, dtype=torch.float16, device=DEV)
+        ops.vae_latent_out(rows, out, batch=2, channels=3, frames=4, h=6, w=10, flip=flip)
+        assert torch.equal(out.cpu(), img[:, :, None].expand(2, 3, 4, 6, 10))
+
+
+@pytest.mark.parametrize("cfg_name,shape", [("tiny", (2, 3, 64, 64)), ("tiny", (1, 3, 64, 128)), ("svd", (1, 3, 128, 256))])
+def test_encoder_matches_oracle(cfg_name, shape):
+    """``vae.encode(image).latent_dist.mode()`` repeated over the frames (ref generate_video_demo.py:139-148): the 2-D
+    encoder with its bottom/right-padded stride-2 convolutions, the single-head mid attention and quant_conv; narrow and
+    real widths (34.2 M parameters); rel-L2 <= 2e-2 against the fp32 oracle (parity unpinned, see its header)."""
+    from oracle.vae_temporal_decoder_ref import encode_image_latents
+    hip, ref = _enc_pair(cfg_name, 7)
+    img = torch.randn(*shape, generator=torch.Generator().manual_seed(13)).clamp(-1.5, 1.5).half()
+    got = hip.encode_image_latents(img.to(DEV), 3)
+    torch.cuda.synchronize()
+    want = encode_image_latents(img.float(), ref, 3)
+    assert got.shape == want.shape and got.dtype == torch.float16 and torch.isfinite(got).all()
+    assert rel_l2(got.float().cpu(), want) <= 2e-2
+    with pytest.raises(ValueError):
+        hip.encode_image_latents(torch.zeros(1, 3, 60, 64, dtype=torch.float16, device=DEV), 3)

@@ -103,6 +103,36 @@ __global__ void frames_out_kernel(const f16 *__restrict__ rows, int64_t ld, cons
   for (int co = 0; co < 3; ++co) dst[co * sc] = (OUT)acc[co];
 }
 
+// Encoder ends.  `flip`: rows hold the image mirrored in both axes (pixel (y, x) at row (H-1-y)*W + (W-1-x)); see
+// models/vae_hip.py::ImageEncoderHIP for why the encoder runs on the mirrored image.
+__global__ void image_pack_kernel(const f16 *__restrict__ img, f16 *__restrict__ out, int h, int w, int cpad, int flip,
+                                  int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;    // one output row
+  if (idx >= total) return;
+  const int64_t hw = (int64_t)h * w, p = idx % hw, b = idx / hw;
+  const int64_t src = flip ? hw - 1 - p : p;
+  f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) v[c] = img[(b * 3 + c) * hw + src];
+  f16 *o = out + idx * cpad;
+  *(f16x8 *)o = v;
+  const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int c = 8; c < cpad; c += 8) *(f16x8 *)(o + c) = z;
+}
+
+// rows [b*hw][ld] channels 0..c-1  ->  out (b, c, frames, h, w), every frame the same image latent
+__global__ void latent_out_kernel(const f16 *__restrict__ rows, int64_t ld, f16 *__restrict__ out, int c, int frames,
+                                  int64_t hw, int flip, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;    // one (b, pixel)
+  if (idx >= total) return;
+  const int64_t p = idx % hw, b = idx / hw;
+  const int64_t src = b * hw + (flip ? hw - 1 - p : p);
+  for (int ch = 0; ch < c; ++ch) {
+    const f16 v = rows[src * ld + ch];
+    for (int f = 0; f < frames; ++f) out[((b * c + ch) * frames + f) * hw + p] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int sp_softmax_rows_f16(void *x, int64_t ld, int64_t rows, int cols, void *stream) {
@@ -156,5 +186,30 @@ extern "C" int sp_vae_frames_out_f16(const void *rows, int64_t ld, const float *
     hipLaunchKernelGGL(frames_out_kernel<f16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const f16 *)rows, ld, weight, bias, (f16 *)out, frames, hw, total, flat0, F, sb, sc, sf);
   SP_CHECK_LAUNCH("sp_vae_frames_out_f16");
+  return SP_OK;
+}
+
+extern "C" int sp_vae_image_pack_f16(const void *image, void *rows, int batch, int h, int w, int cpad, int flip,
+                                     void *stream) {
+  SP_REQUIRE(image && rows, "sp_vae_image_pack_f16: null pointer");
+  SP_REQUIRE(batch > 0 && h > 0 && w > 0 && cpad >= 8 && cpad % 8 == 0, "sp_vae_image_pack_f16: bad shape / cpad=%d", cpad);
+  const int64_t total = (int64_t)batch * h * w;
+  SP_CLEAR_STALE_ERROR();
+  hipLaunchKernelGGL(image_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const f16 *)image, (f16 *)rows, h, w, cpad, flip, total);
+  SP_CHECK_LAUNCH("sp_vae_image_pack_f16");
+  return SP_OK;
+}
+
+extern "C" int sp_vae_latent_out_f16(const void *rows, int64_t ld, void *out, int batch, int channels, int frames, int h,
+                                     int w, int flip, void *stream) {
+  SP_REQUIRE(rows && out, "sp_vae_latent_out_f16: null pointer");
+  SP_REQUIRE(batch > 0 && channels > 0 && frames > 0 && h > 0 && w > 0 && ld >= channels,
+             "sp_vae_latent_out_f16: bad shape (ld=%lld, channels=%d)", (long long)ld, channels);
+  const int64_t hw = (int64_t)h * w, total = (int64_t)batch * hw;
+  SP_CLEAR_STALE_ERROR();
+  hipLaunchKernelGGL(latent_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const f16 *)rows, ld, (f16 *)out, channels, frames, hw, flip, total);
+  SP_CHECK_LAUNCH("sp_vae_latent_out_f16");
   return SP_OK;
 }

@@ -66,6 +66,11 @@ SIGNATURES = {
     "sp_softmax_rows_f16": (_I, [_P, _L, _L, _I, _P]),
     "sp_vae_pack_latent_f16": (_I, [_P, _P, _F, _L, _I, _I, _L, _L, _L, _I, _I, _I, _P]),
     "sp_vae_frames_out_f16": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _L, _L, _P]),
+    "sp_vae_image_pack_f16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "sp_vae_latent_out_f16": (_I, [_P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sp_patchify_f16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "sp_attn_small_f16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _F, _P]),
+    "sp_gelu_f16": (_I, [_P, _P, _L, _I, _P]),
     "sp_dummy_unet_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _F, _I, _I, _I, _I, _I, _I, _P]),
 }
 

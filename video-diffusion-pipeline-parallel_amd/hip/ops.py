@@ -267,6 +267,36 @@ def vae_frames_out(rows, weight, bias, out, *, batch, frames, h, w, flat0, frame
     return out
 
 
+def vae_image_pack(image, rows, *, batch, h, w, cpad, flip):
+    _check(load().sp_vae_image_pack_f16(_f16(image, "image").data_ptr(), _f16(rows, "rows").data_ptr(), batch, h, w, cpad,
+                                        int(flip), _stream()), "sp_vae_image_pack_f16")
+    return rows
+
+
+def vae_latent_out(rows, out, *, batch, channels, frames, h, w, flip):
+    _check(load().sp_vae_latent_out_f16(_f16(rows, "rows").data_ptr(), rows.shape[1], _f16(out, "out").data_ptr(), batch,
+                                        channels, frames, h, w, int(flip), _stream()), "sp_vae_latent_out_f16")
+    return out
+
+
+def patchify(pixels, rows, *, batch, h, w, patch, kpad):
+    _check(load().sp_patchify_f16(_f16(pixels, "pixels").data_ptr(), _f16(rows, "rows").data_ptr(), batch, h, w, patch, kpad,
+                                  _stream()), "sp_patchify_f16")
+    return rows
+
+
+def attn_small(q, k, v, o, *, ldq, ldk, ldv, ldo, batch, seq, heads, head_dim, scale):
+    with _Timed("attn_small", 4.0 * batch * heads * seq * seq * head_dim):
+        _check(load().sp_attn_small_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), ldq, ldk, ldv, ldo, batch, seq,
+                                        heads, head_dim, scale, _stream()), "sp_attn_small_f16")
+    return o
+
+
+def gelu(x, y, *, quick=False):
+    _check(load().sp_gelu_f16(_f16(x, "x").data_ptr(), _f16(y, "y").data_ptr(), x.numel(), int(quick), _stream()), "sp_gelu_f16")
+    return y
+
+
 def euler_step(latent, eps_cond, eps_uncond, guidance, out, *, ld_eps, sigma, sigma_next, b, frames, h, w):
     _check(load().sp_euler_step_f16(latent.data_ptr(), eps_cond.data_ptr(), _ptr(eps_uncond), ld_eps, _ptr(guidance),
                                     out.data_ptr(), sigma, sigma_next, b, frames, h, w, _stream()), "sp_euler_step_f16")

@@ -129,57 +129,75 @@ def param_count(cfg: VAEDecoderConfig) -> int:
     return sum(math.prod(s) for _, s, _ in param_inventory(cfg))
 
 
-# ---------------------------------------------------------------------------------------------- engine
-class TemporalDecoderHIP:
-    """``AutoencoderKLTemporalDecoder.decode`` on a HIP device.  ``state_dict``: the ``decoder.*`` entries of a diffusers
-    vae checkpoint with the prefix stripped (or ``random_state_dict``)."""
+def encoder_param_inventory(cfg: VAEDecoderConfig, in_channels: int = 3) -> Iterator[tuple]:
+    """(name, shape, fan) of ``AutoencoderKLTemporalDecoder.encoder`` (keys ``encoder.*``) and ``quant_conv``."""
 
-    def __init__(self, cfg: VAEDecoderConfig, state_dict: dict, device):
+    def conv(p, cin, cout, k):
+        yield p + ".weight", (cout, cin) + k, cin * math.prod(k)
+        yield p + ".bias", (cout,), cin * math.prod(k)
+
+    def norm(p, c):
+        yield p + ".weight", (c,), 0
+        yield p + ".bias", (c,), -1
+
+    def res(p, cin, cout):
+        yield from norm(p + ".norm1", cin)
+        yield from conv(p + ".conv1", cin, cout, (3, 3))
+        yield from norm(p + ".norm2", cout)
+        yield from conv(p + ".conv2", cout, cout, (3, 3))
+        if cin != cout:
+            yield from conv(p + ".conv_shortcut", cin, cout, (1, 1))
+
+    ch = list(cfg.block_out_channels)
+    yield from conv("encoder.conv_in", in_channels, ch[0], (3, 3))
+    prev = ch[0]
+    for i, c in enumerate(ch):
+        for j in range(cfg.layers_per_block):
+            yield from res(f"encoder.down_blocks.{i}.resnets.{j}", prev if j == 0 else c, c)
+        if i != len(ch) - 1:
+            yield from conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", c, c, (3, 3))
+        prev = c
+    c = ch[-1]
+    yield from res("encoder.mid_block.resnets.0", c, c)
+    a = "encoder.mid_block.attentions.0"
+    yield from norm(a + ".group_norm", c)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        yield a + f".{n}.weight", (c, c), c
+        yield a + f".{n}.bias", (c,), c
+    yield from res("encoder.mid_block.resnets.1", c, c)
+    yield from norm("encoder.conv_norm_out", c)
+    yield from conv("encoder.conv_out", c, 2 * cfg.latent_channels, (3, 3))
+    yield from conv("quant_conv", 2 * cfg.latent_channels, 2 * cfg.latent_channels, (1, 1))
+
+
+def random_encoder_state_dict(cfg: VAEDecoderConfig, seed: int = 0, device="cpu", dtype=torch.float16) -> dict:
+    gen = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, shape, fan in encoder_param_inventory(cfg):
+        if fan > 0:
+            t = (torch.rand(shape, generator=gen, device=device) * 2 - 1) / math.sqrt(fan)
+        elif fan == 0:
+            t = 1.0 + 0.1 * (torch.rand(shape, generator=gen, device=device) - 0.5)
+        else:
+            t = 0.1 * (torch.rand(shape, generator=gen, device=device) - 0.5)
+        sd[name] = t.to(dtype)
+    return sd
+
+
+# ---------------------------------------------------------------------------------------------- engine
+class _VAEKernels:
+    """Kernel helpers shared by the decoder and the encoder engines."""
+
+    def _init_common(self, cfg, device):
         self.cfg = cfg
         self.device = dev = torch.device(device)
         if dev.type != "cuda":
-            raise RuntimeError("TemporalDecoderHIP runs on an MI355X HIP device only (no CPU fallback)")
+            raise RuntimeError(f"{type(self).__name__} runs on an MI355X HIP device only (no CPU fallback)")
         ops.load()  # fail loudly now if the extension is missing
-        sd = state_dict
-        ch = list(cfg.block_out_channels)
-        c = ch[-1]
-        if any(v % 64 for v in ch):
+        if any(v % 64 for v in cfg.block_out_channels):
             raise ValueError("block_out_channels must be multiples of 64 (MFMA K-steps)")
-        self.conv_in = _Dense.conv3x3(sd, "conv_in", dev)
-        self.mid = (self._res(sd, "mid_block.resnets.0", c, c), self._attn(sd, "mid_block.attentions.0", c),
-                    self._res(sd, "mid_block.resnets.1", c, c))
-        self.up = []
-        rev = list(reversed(ch))
-        prev = rev[0]
-        for i, co in enumerate(rev):
-            res = [self._res(sd, f"up_blocks.{i}.resnets.{j}", prev if j == 0 else co, co)
-                   for j in range(cfg.layers_per_block + 1)]
-            us = _Dense.conv3x3(sd, f"up_blocks.{i}.upsamplers.0.conv", dev) if i != len(rev) - 1 else None
-            self.up.append((res, us))
-            prev = co
-        self.norm_out = _Norm(sd, "conv_norm_out", dev, 1e-6)
-        # conv_out: 3 real output channels, stored as 8 columns (16-byte rows for frames_out's reads)
-        w, b = sd["conv_out.weight"], sd["conv_out.bias"]
-        w8 = torch.zeros((8,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
-        b8 = torch.zeros(8, dtype=b.dtype, device=b.device)
-        w8[:cfg.out_channels], b8[:cfg.out_channels] = w, b
-        self.conv_out = _Dense.conv3x3({"c.weight": w8, "c.bias": b8}, "c", dev)
-        if cfg.out_channels != 3:
-            raise ValueError("time_conv_out kernel is written for 3 output channels")
-        self.tco_w = _f32(sd["time_conv_out.weight"][:, :, :, 0, 0], dev)      # [out][in][tap]
-        self.tco_b = _f32(sd["time_conv_out.bias"], dev)
         self._ws = {}
-
-    def _res(self, sd, p, cin, cout):
-        dev = self.device
-        s, t = p + ".spatial_res_block", p + ".temporal_res_block"
-        sig = float(torch.sigmoid(sd[p + ".time_mixer.mix_factor"].float()).item())
-        return dict(cin=cin, cout=cout, temporal_weight=sig,          # blend = (1 - sig)*spatial + sig*temporal
-                    n1=_Norm(sd, s + ".norm1", dev, 1e-6), c1=_Dense.conv3x3(sd, s + ".conv1", dev),
-                    n2=_Norm(sd, s + ".norm2", dev, 1e-6), c2=_Dense.conv3x3(sd, s + ".conv2", dev),
-                    sc=_Dense.linear(sd, s + ".conv_shortcut", dev) if cin != cout else None,
-                    tn1=_Norm(sd, t + ".norm1", dev, 1e-5), tc1=_Dense.tconv(sd, t + ".conv1", dev),
-                    tn2=_Norm(sd, t + ".norm2", dev, 1e-5), tc2=_Dense.tconv(sd, t + ".conv2", dev))
+        return dev
 
     def _attn(self, sd, p, c):
         dev = self.device
@@ -188,7 +206,6 @@ class TemporalDecoderHIP:
                     wv=sd[p + ".to_v.weight"].to(dev, torch.float16).contiguous(),      # A operand of V^T = W_v X^T
                     bv=_f32(sd[p + ".to_v.bias"], dev), out=_Dense.linear(sd, p + ".to_out.0", dev))
 
-    # ------------------------------------------------------------------ kernel helpers
     def _buf(self, rows, c):
         return torch.empty((rows, c), dtype=torch.float16, device=self.device)
 
@@ -213,6 +230,72 @@ class TemporalDecoderHIP:
                       silu=silu, ws=ws)
         return y
 
+    def _run_attn(self, p, x, n_img, hw):
+        """diffusers ``Attention(heads=1, dim_head=C, norm_num_groups=32, residual_connection=True)`` per image."""
+        c, m = p["c"], n_img * hw
+        if hw % 64:
+            raise ValueError(f"mid-block attention: H*W = {hw} tokens per image must be a multiple of 64")
+        t = self._gn(p["norm"], x, n_img, hw, False)
+        q = self._gemm(p["q"], t, m)
+        k = self._gemm(p["k"], t, m)
+        o = self._buf(m, c)
+        scores = self._buf(hw, hw)
+        vt = self._buf(c, hw)
+        scale = 1.0 / math.sqrt(c)
+        for i in range(n_img):
+            r = slice(i * hw, (i + 1) * hw)
+            ops.gemm(q[r], k[r], scores, m=hw, n=hw, cin=c, oscale=scale)                 # S = Q K^T / sqrt(C)
+            ops.softmax_rows(scores, rows=hw, cols=hw)
+            ops.gemm(p["wv"], t[r], vt, m=c, n=hw, cin=c)                                 # V^T = W_v X^T   [C][tokens]
+            ops.gemm(scores, vt, o[r], m=hw, n=c, cin=hw, bias=p["bv"])                    # O = P V + b_v
+        del scores, vt, q, k, t
+        return self._gemm(p["out"], o, m, res1=x, r1scale=1.0)
+
+
+class TemporalDecoderHIP(_VAEKernels):
+    """``AutoencoderKLTemporalDecoder.decode`` on a HIP device.  ``state_dict``: the ``decoder.*`` entries of a diffusers
+    vae checkpoint with the prefix stripped (or ``random_state_dict``)."""
+
+    def __init__(self, cfg: VAEDecoderConfig, state_dict: dict, device):
+        dev = self._init_common(cfg, device)
+        sd = state_dict
+        ch = list(cfg.block_out_channels)
+        c = ch[-1]
+        self.conv_in = _Dense.conv3x3(sd, "conv_in", dev)
+        self.mid = (self._res(sd, "mid_block.resnets.0", c, c), self._attn(sd, "mid_block.attentions.0", c),
+                    self._res(sd, "mid_block.resnets.1", c, c))
+        self.up = []
+        rev = list(reversed(ch))
+        prev = rev[0]
+        for i, co in enumerate(rev):
+            res = [self._res(sd, f"up_blocks.{i}.resnets.{j}", prev if j == 0 else co, co)
+                   for j in range(cfg.layers_per_block + 1)]
+            us = _Dense.conv3x3(sd, f"up_blocks.{i}.upsamplers.0.conv", dev) if i != len(rev) - 1 else None
+            self.up.append((res, us))
+            prev = co
+        self.norm_out = _Norm(sd, "conv_norm_out", dev, 1e-6)
+        # conv_out: 3 real output channels, stored as 8 columns (16-byte rows for frames_out's reads)
+        w, b = sd["conv_out.weight"], sd["conv_out.bias"]
+        w8 = torch.zeros((8,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+        b8 = torch.zeros(8, dtype=b.dtype, device=b.device)
+        w8[:cfg.out_channels], b8[:cfg.out_channels] = w, b
+        self.conv_out = _Dense.conv3x3({"c.weight": w8, "c.bias": b8}, "c", dev)
+        if cfg.out_channels != 3:
+            raise ValueError("time_conv_out kernel is written for 3 output channels")
+        self.tco_w = _f32(sd["time_conv_out.weight"][:, :, :, 0, 0], dev)      # [out][in][tap]
+        self.tco_b = _f32(sd["time_conv_out.bias"], dev)
+
+    def _res(self, sd, p, cin, cout):
+        dev = self.device
+        s, t = p + ".spatial_res_block", p + ".temporal_res_block"
+        sig = float(torch.sigmoid(sd[p + ".time_mixer.mix_factor"].float()).item())
+        return dict(cin=cin, cout=cout, temporal_weight=sig,          # blend = (1 - sig)*spatial + sig*temporal
+                    n1=_Norm(sd, s + ".norm1", dev, 1e-6), c1=_Dense.conv3x3(sd, s + ".conv1", dev),
+                    n2=_Norm(sd, s + ".norm2", dev, 1e-6), c2=_Dense.conv3x3(sd, s + ".conv2", dev),
+                    sc=_Dense.linear(sd, s + ".conv_shortcut", dev) if cin != cout else None,
+                    tn1=_Norm(sd, t + ".norm1", dev, 1e-5), tc1=_Dense.tconv(sd, t + ".conv1", dev),
+                    tn2=_Norm(sd, t + ".norm2", dev, 1e-5), tc2=_Dense.tconv(sd, t + ".conv2", dev))
+
     # ------------------------------------------------------------------ blocks
     def _run_res(self, p, x, b, f, h, w):
         """SpatioTemporalResBlock(temb_channels=None): ResnetBlock2D per frame, TemporalResnetBlock over the frames,
@@ -230,27 +313,6 @@ class TemporalDecoderHIP:
         t = self._gn(p["tn2"], t, b, f * hw, True)
         # (1-sig)*s + sig*(s + conv2(t)) = s + sig*conv2(t)
         return self._gemm(p["tc2"], t, m, temporal=(f, hw), oscale=p["temporal_weight"], res1=s, r1scale=1.0)
-
-    def _run_attn(self, p, x, n_img, hw):
-        """diffusers ``Attention(heads=1, dim_head=C, norm_num_groups=32, residual_connection=True)`` per frame."""
-        c, m = p["c"], n_img * hw
-        if hw % 64:
-            raise ValueError(f"mid-block attention: H*W = {hw} tokens per frame must be a multiple of 64")
-        t = self._gn(p["norm"], x, n_img, hw, False)
-        q = self._gemm(p["q"], t, m)
-        k = self._gemm(p["k"], t, m)
-        o = self._buf(m, c)
-        scores = self._buf(hw, hw)
-        vt = self._buf(c, hw)
-        scale = 1.0 / math.sqrt(c)
-        for i in range(n_img):
-            r = slice(i * hw, (i + 1) * hw)
-            ops.gemm(q[r], k[r], scores, m=hw, n=hw, cin=c, oscale=scale)                 # S = Q K^T / sqrt(C)
-            ops.softmax_rows(scores, rows=hw, cols=hw)
-            ops.gemm(p["wv"], t[r], vt, m=c, n=hw, cin=c)                                 # V^T = W_v X^T   [C][tokens]
-            ops.gemm(scores, vt, o[r], m=hw, n=c, cin=hw, bias=p["bv"])                    # O = P V + b_v
-        del scores, vt, q, k, t
-        return self._gemm(p["out"], o, m, res1=x, r1scale=1.0)
 
     # ------------------------------------------------------------------ public
     def _decode_chunk(self, src, src_strides, dst, dst_strides, *, flat0, n, frames_per_item, batch, frames, h, w,
@@ -312,4 +374,97 @@ class TemporalDecoderHIP:
             n = min(decode_chunk_size, b * f - i)
             self._decode_chunk(latents, (c * f * hw, f * hw, hw), out, (3 * f * ohw, f * ohw, ohw), flat0=i, n=n,
                                frames_per_item=f, batch=1, frames=n, h=h, w=w, scale=1.0 / self.cfg.scaling_factor)
+        return out
+
+
+class ImageEncoderHIP(_VAEKernels):
+    """``vae.encode(image).latent_dist.mode()`` of the reference's ``encode_image``
+    (``/root/reference/scripts/generate_video_demo.py:117-148``) on a HIP device: the 2-D encoder of
+    ``AutoencoderKLTemporalDecoder`` + ``quant_conv``, mean half only.  ``state_dict``: the checkpoint's ``encoder.*``
+    and ``quant_conv.*`` entries (or ``random_encoder_state_dict``).
+
+    Downsample2D pads BOTTOM/RIGHT by one and strides by two without padding; the implicit-GEMM kernel's stride-2
+    gather pads symmetrically, which for an even size is exactly "top/left only".  The engine therefore runs the whole
+    encoder on the image mirrored in both axes with every 3x3 kernel mirrored as well (GroupNorm, the 1x1 shortcuts
+    and the attention do not care about pixel order), and un-mirrors the 4-channel latent while writing it out: no
+    padded copies, no extra kernel variant.  ``quant_conv`` (1x1 on 8 channels) is composed into ``conv_out`` at load
+    time (fp32, rounded once), keeping only the four mean channels that ``mode()`` returns."""
+
+    def __init__(self, cfg: VAEDecoderConfig, state_dict: dict, device):
+        dev = self._init_common(cfg, device)
+        sd = dict(state_dict)
+        ch = list(cfg.block_out_channels)
+        lc = cfg.latent_channels
+        # compose quant_conv into conv_out (mean channels only), 8 stored columns
+        wq = sd["quant_conv.weight"].float()[:lc, :, 0, 0]                                   # (lc, 2lc)
+        wc, bc = sd["encoder.conv_out.weight"].float(), sd["encoder.conv_out.bias"].float()
+        w8 = torch.zeros((8,) + tuple(wc.shape[1:]))
+        b8 = torch.zeros(8)
+        w8[:lc] = torch.einsum("oc,cikl->oikl", wq, wc)
+        b8[:lc] = wq @ bc + sd["quant_conv.bias"].float()[:lc]
+        sd["encoder.conv_out_q.weight"], sd["encoder.conv_out_q.bias"] = w8, b8
+        for k in list(sd):                      # mirror every 3x3 kernel (see class docstring)
+            if k.endswith(".weight") and sd[k].dim() == 4 and sd[k].shape[-1] == 3:
+                sd[k] = sd[k].flip(-1, -2)
+        e = "encoder"
+        self.conv_in = _Dense.conv3x3(sd, e + ".conv_in", dev)
+        self.down = []
+        prev = ch[0]
+        for i, c in enumerate(ch):
+            res = [self._res2d(sd, f"{e}.down_blocks.{i}.resnets.{j}", prev if j == 0 else c, c)
+                   for j in range(cfg.layers_per_block)]
+            ds = _Dense.conv3x3(sd, f"{e}.down_blocks.{i}.downsamplers.0.conv", dev) if i != len(ch) - 1 else None
+            self.down.append((res, ds))
+            prev = c
+        c = ch[-1]
+        self.mid = (self._res2d(sd, e + ".mid_block.resnets.0", c, c), self._attn(sd, e + ".mid_block.attentions.0", c),
+                    self._res2d(sd, e + ".mid_block.resnets.1", c, c))
+        self.norm_out = _Norm(sd, e + ".conv_norm_out", dev, 1e-6)
+        self.conv_out = _Dense.conv3x3(sd, e + ".conv_out_q", dev)
+        self.levels = len(ch) - 1
+
+    def _res2d(self, sd, p, cin, cout):
+        dev = self.device
+        return dict(n1=_Norm(sd, p + ".norm1", dev, 1e-6), c1=_Dense.conv3x3(sd, p + ".conv1", dev),
+                    n2=_Norm(sd, p + ".norm2", dev, 1e-6), c2=_Dense.conv3x3(sd, p + ".conv2", dev),
+                    sc=_Dense.linear(sd, p + ".conv_shortcut", dev) if cin != cout else None)
+
+    def _run_res2d(self, p, x, n, h, w):
+        m, geom = n * h * w, (n, h, w, h, w, 1, 0)
+        t = self._gn(p["n1"], x, n, h * w, True)
+        t = self._gemm(p["c1"], t, m, conv=geom)
+        t = self._gn(p["n2"], t, n, h * w, True)
+        skip = x if p["sc"] is None else self._gemm(p["sc"], x, m)
+        return self._gemm(p["c2"], t, m, conv=geom, res1=skip, r1scale=1.0)
+
+    def encode_image_latents(self, image, num_frames: int):
+        """image: fp16 (B, 3, H, W) in [-1, 1], noise augmentation already added (ref :126-136).  Returns the
+        ``image_latents`` of ``StableVideoUNet.set_conditioning``: fp16 (B, 4, num_frames, H/8, W/8), every frame the
+        same latent (ref :139-148), no scaling factor."""
+        if image.dim() != 4 or image.shape[1] != 3:
+            raise ValueError(f"image must be (B, 3, H, W); got {tuple(image.shape)}")
+        if image.dtype != torch.float16 or image.device != self.device or not image.is_contiguous():
+            raise TypeError("image must be a contiguous float16 tensor on this encoder's device")
+        n, _, h, w = image.shape
+        f = 1 << self.levels
+        if h % f or w % f or num_frames <= 0:
+            raise ValueError(f"image height/width must be multiples of {f}, num_frames positive")
+        if ((h // f) * (w // f)) % 64:
+            raise ValueError("mid-block attention: (H/8)*(W/8) tokens must be a multiple of 64")
+        rows = self._buf(n * h * w, self.conv_in.cin)
+        ops.vae_image_pack(image, rows, batch=n, h=h, w=w, cpad=self.conv_in.cin, flip=True)
+        x = self._gemm(self.conv_in, rows, n * h * w, conv=(n, h, w, h, w, 1, 0))
+        for res, ds in self.down:
+            for p in res:
+                x = self._run_res2d(p, x, n, h, w)
+            if ds is not None:
+                x = self._gemm(ds, x, n * (h // 2) * (w // 2), conv=(n, h, w, h // 2, w // 2, 2, 0))
+                h, w = h // 2, w // 2
+        x = self._run_res2d(self.mid[0], x, n, h, w)
+        x = self._run_attn(self.mid[1], x, n, h * w)
+        x = self._run_res2d(self.mid[2], x, n, h, w)
+        x = self._gn(self.norm_out, x, n, h * w, True)
+        x = self._gemm(self.conv_out, x, n * h * w, conv=(n, h, w, h, w, 1, 0))
+        out = torch.empty((n, self.cfg.latent_channels, num_frames, h, w), dtype=torch.float16, device=self.device)
+        ops.vae_latent_out(x, out, batch=n, channels=self.cfg.latent_channels, frames=num_frames, h=h, w=w, flip=True)
         return out
