@@ -211,3 +211,55 @@ def test_encoder_matches_oracle(cfg_name, shape):
     assert rel_l2(got.float().cpu(), want) <= 2e-2
     with pytest.raises(ValueError):
         hip.encode_image_latents(torch.zeros(1, 3, 60, 64, dtype=torch.float16, device=DEV), 3)
+
+
+def test_image_to_video_flow_through_the_edge_stages():
+    """The reference demo's data flow at toy size (scripts/generate_video_demo.py: encode_image -> set_conditioning ->
+    denoising steps through the pipeline executor -> decode_latents), every stage on its HIP engine: shapes, dtypes and
+    finiteness at each boundary, and the edge stages equal their oracles on the very tensors that flowed through."""
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from oracle.vae_temporal_decoder_ref import decode_latents as ref_decode, encode_image_latents
+    from vdpp_amd.models.clip_hip import CLIPVisionHIP, CLIPVisionSpec
+    from vdpp_amd.models.edge_stages import decode_latents, encode_image
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+    from vdpp_amd.models.unet_hip import SVDUNetHIP
+    from vdpp_amd.models.unet_spec import UNetConfig, random_state_dict
+    from vdpp_amd.pipeline import LatentSpec, run_single_latent
+
+    frames, h, w, steps = 3, 8, 16, 2
+    ucfg = UNetConfig.tiny(64)                                         # cross_attention_dim 128
+    ccfg = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=56,
+                            patch_size=14, projection_dim=ucfg.cross_attention_dim)
+    torch.manual_seed(3)
+    clip_ref = CLIPVisionModelWithProjection(ccfg).eval()
+    with torch.no_grad():
+        for p in clip_ref.parameters():
+            p.copy_(p.half().float())
+    clip = CLIPVisionHIP(CLIPVisionSpec.from_config(ccfg), {k: v.half() for k, v in clip_ref.state_dict().items()}, DEV)
+    enc, enc_ref = _enc_pair("tiny", 17)
+    dec, dec_ref = _pair("tiny", 19)
+    g = torch.Generator().manual_seed(23)
+    pixel_values = torch.randn(1, 3, 56, 56, generator=g).half()
+    image = torch.randn(1, 3, 8 * h, 8 * w, generator=g).clamp(-1, 1).half()
+    noise = torch.randn(1, 3, 8 * h, 8 * w, generator=g).half()
+
+    emb, img_lat = encode_image(pixel_values, image, clip, enc, frames, noise=noise, noise_aug_strength=0.02)
+    assert emb.shape == (1, 1, ucfg.cross_attention_dim) and img_lat.shape == (1, 4, frames, h, w)
+    with torch.no_grad():
+        assert rel_l2(emb.float().cpu(), clip_ref(pixel_values.float()).image_embeds.unsqueeze(1)) <= 1e-2
+    noisy = (image.float() + 0.02 * noise.float()).half().float()
+    assert rel_l2(img_lat.float().cpu(), encode_image_latents(noisy, enc_ref, frames)) <= 2e-2
+
+    unet = SVDUNetHIP(ucfg, random_state_dict(ucfg, seed=0, dtype=torch.float16), DEV)
+    model = StableVideoUNet(unet=unet, timesteps=StableVideoUNet._default_timestep_schedule(steps))
+    model.set_conditioning(emb, img_lat, num_frames=frames)
+    lat = (torch.randn(1, 4, frames, h, w, generator=g) * model.init_noise_sigma).half().to(DEV)
+    spec = LatentSpec(shape=lat.shape, dtype=torch.float16, device=torch.device(DEV))
+    out = run_single_latent(model, total_steps=steps, timesteps=list(range(steps)), world_size=1, rank=0, latent_spec=spec,
+                            input_latent=lat)
+    assert out.shape == lat.shape and torch.isfinite(out).all()
+
+    video = decode_latents(out, dec, frames)
+    torch.cuda.synchronize()
+    assert video.shape == (1, 3, frames, 8 * h, 8 * w) and video.dtype == torch.float32 and torch.isfinite(video).all()
+    assert rel_l2(video.cpu(), ref_decode(out.float().cpu(), dec_ref, frames)) <= 2e-2

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Fold the three PMC passes of tools/pmc_forward.sh into a per-kernel table (second half of the dispatches =
 the profiled step).  HBM bytes: FETCH_SIZE is in KB and reads HALF the bytes of wide coalesced streams on gfx950
-(MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE (KB) is exact for 16-byte streaming stores."""
+(MI355X_MICROARCH.md, HBM section) -> doubled.  The factor was calibrated in round 3 on known byte counts in the GEMM
+kernels' own access shapes (profiles/r03_fetch_size_calibration.txt, tools/dma_probe calib): 1.986 for LDS-DMA pieces
+of 16 rows x 64 B (the K-step shape), 2.000 for 8 x 128 B, paired halves, contiguous KiB and register loads -- so x2
+holds for every kernel family here.  WRITE_SIZE (KB) is exact for 16-byte streaming stores."""
 import csv, glob, sys, collections, re
 root = sys.argv[1]
 def load(sub):
@@ -61,5 +64,6 @@ if len(sys.argv) > 2:
                "kernel": "implicit-GEMM kernels (gemm_pp_kernel<*>, gemm_ps_kernel<*>, gemm_f16_kernel<*>)",
                "commit": sys.argv[3] if len(sys.argv) > 3 else "unknown",
                "fabric_read_bytes": rd, "write_bytes": wr, "launches": int(n),
-               "note": "read bytes = 2 x FETCH_SIZE (gfx950 half-count correction), Infinity-Cache hits included"},
+               "note": "read bytes = 2 x FETCH_SIZE (gfx950 half-count correction, calibrated on this kernel family's access "
+                       "shapes: profiles/r03_fetch_size_calibration.txt), Infinity-Cache hits included"},
               open(sys.argv[2], "w"), indent=1)
