@@ -511,11 +511,13 @@ def _attn_fp8(ops, d, c, batch, seq, heads):
 
 @pytest.mark.parametrize("batch,seq,heads", [(2, 128, 1), (3, 200, 2), (1, 6, 1), (2, 576, 5), (1, 1000, 3), (1, 2304, 2)])
 def test_attention_spatial_fp8(batch, seq, heads):
-    """fp8-e4m3 MFMA attention (BASELINE config 5).  Error budget on i.i.d. N(0,1) q/k/v, the worst case for a
-    3-bit mantissa (measured on MI355X): 2.2e-2 rel-L2 from rounding P to e4m3 (checked against fp32 attention on
-    the e4m3-rounded q/k/v, bound 2.6e-2) and 5.2e-2 in total once the rounding of q, k (score error ~3 %) and v is
-    included (checked against fp32 attention on the unrounded inputs, bound 6e-2).  The <= 3e-2 of SURVEY 8c is
-    asserted where it is meaningful, at the UNet boundary (test_unet_forward_fp8_attention_matches_oracle)."""
+    """fp8-e4m3 MFMA attention (BASELINE config 5; parity path, not the default: DESIGN.md section 3).  Error budget on
+    i.i.d. N(0,1) q/k/v, the worst case for a 3-bit mantissa (measured on MI355X): 2.2e-2 rel-L2 from rounding P to e4m3
+    (checked against fp32 attention on the e4m3-rounded q/k/v; the ONE op-level bound, 4e-2 for any row length and
+    amplitude, is what tools/fuzz_misc.py enforces; these fixed unit-variance cases stay under 2.6e-2) and 5.2e-2 in total
+    once the rounding of q, k (score error ~3 %) and v is included (against fp32 attention on the unrounded inputs,
+    bound 6e-2).  The <= 3e-2 of SURVEY 8c is asserted where it is meaningful, at the UNet boundary
+    (test_unet_forward_fp8_attention_matches_oracle)."""
     ops = _ops()
     g = torch.Generator().manual_seed(seq + 7)
     c = heads * 64

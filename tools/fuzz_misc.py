@@ -47,10 +47,11 @@ def attn_spatial(rng, g, fp8):
         ws = torch.empty(ops.attn_fp8_ws_bytes(batch, seq, heads), dtype=torch.uint8, device=DEV)
         ops.attn_spatial_fp8(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o, ws, **kw)
         x = qkv.clamp(-448, 448).to(torch.float8_e4m3fn).float()
-        # 3e-2 is the budget at unit-variance inputs (2.2e-2 from rounding P to e4m3); at twice the amplitude
-        # the softmax is peaked, a handful of 3-bit-mantissa probabilities carry a row and their rounding averages less
-        # (likewise short rows: fewer rounded probabilities per output)
-        tol = 3e-2 if (amp <= 1.0 and seq >= 256) else 4e-2
+        # ONE op-level bound for every row length and amplitude (DESIGN.md section 3, fp8 paragraph): 4e-2 relative L2
+        # against fp32 attention of the e4m3-rounded inputs.  (2.2e-2 is what rounding P to e4m3 costs on long rows of
+        # unit-variance inputs; peaked softmaxes and short rows average fewer rounded probabilities per output.)  The
+        # 3e-2 of SURVEY 8c is asserted at the UNet boundary, where it is meaningful.
+        tol = 4e-2
     else:
         ops.attn_spatial(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o, **kw)
         x, tol = qkv, 3e-3

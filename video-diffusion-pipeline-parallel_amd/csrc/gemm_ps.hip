@@ -220,8 +220,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
 
   // output addressing of this lane: even 16-lane rows own 8 channels of the first sub-tile of a pair, odd rows of the second
   const int ocol = (fq & 1) * 16 + (fq >> 1) * 8;  // column of the 16-byte piece inside a pair of sub-tiles (32 columns)
-  const __amdgpu_buffer_rsrc_t d_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void *)p.d, 0, (int)min((int64_t)p.m * p.ldd * 2, (int64_t)0x7fffffff), 0x00020000);
+#ifdef SP_GEMM_EXPERIMENTS
+  // timing-only probe (dbg & 32): zero records -> the range check drops every store, the instruction stream stays
+  const int d_bytes = (p.dbg & 32) ? 0 : (int)min((int64_t)p.m * p.ldd * 2, (int64_t)0x7fffffff);
+#else
+  const int d_bytes = (int)min((int64_t)p.m * p.ldd * 2, (int64_t)0x7fffffff);
+#endif
+  const __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.d, 0, d_bytes, 0x00020000);
 
   if constexpr (PAIR) {
     if (late) wait_vm<2 * L_LATE>(); else wait_vm<2 * L_EARLY>();  // K-steps 0 and 1 landed (this wave's part)

@@ -16,7 +16,7 @@ namespace {
 __host__ __device__ inline int gn_rows_per_iter(int oc) { int p = 512 / oc; return p < 1 ? 1 : p; }
 
 __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ part, int64_t rows,
-                                int c, int groups, int splits) {
+                                int c, int groups, int splits, int64_t per) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *sh = (float *)smem;                      // [P][C][2], then [parts][groups][2] behind it
   const int oc = c >> 3;
@@ -24,14 +24,12 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
   const int tid = threadIdx.x;
   const int o = tid % oc, pr = tid / oc;
   const int inst = blockIdx.x, split = blockIdx.y;
-  const int64_t per = (rows + splits - 1) / splits;
-  const int64_t r0 = (int64_t)split * per;
-  int64_t r1 = r0 + per; if (r1 > rows) r1 = rows;
+  const int64_t r0 = (int64_t)split * per;        // per: a multiple of 4*P (host), so every block but the last runs
+  int64_t r1 = r0 + per; if (r1 > rows) r1 = rows;   // whole batches of four rows per thread
   float s[8], ss[8], ref[8];
   const int cpg = c / groups;
   {
-    // the group's first element of the instance's first row, for each of this thread's 8 channels: one 16-byte load
-    // of the octet that holds it per distinct group (an octet spans at most two groups when cpg >= 8)
+    // the group's first element of the instance's first row, for each of this thread's 8 channels
     const f16 *row0 = x + ((int64_t)inst * rows) * c;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -41,16 +39,29 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
   }
   const f16 *base = x + ((int64_t)inst * rows) * c + o * 8;
   if (pr < P) {
-    // eight independent 16-byte loads in flight per thread (memory-level parallelism), then accumulate
-    int64_t r = r0 + pr;
-    for (; r + 7 * (int64_t)P < r1; r += 8 * (int64_t)P) {
-      f16x8 v[8];
+    // batches of four independent 16-byte loads per thread, double-buffered: the next batch is in flight while this one
+    // is accumulated (a block has only ~10 row-iterations: without the overlap it is a chain of exposed round trips)
+    auto acc4 = [&](const f16x8 (&v)[4]) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *(const f16x8 *)(base + (r + (int64_t)u * P) * c);
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e] - ref[e]; s[e] += f; ss[e] += f * f; }
+    };
+    int64_t r = r0 + pr;
+    const int64_t step = 4 * (int64_t)P;
+    if (r + 3 * (int64_t)P < r1) {
+      f16x8 va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) va[u] = *(const f16x8 *)(base + (r + (int64_t)u * P) * c);
+      r += step;
+      for (; r + 3 * (int64_t)P < r1; r += step) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vb[u] = *(const f16x8 *)(base + (r + (int64_t)u * P) * c);
+        acc4(va);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) va[u] = vb[u];
+      }
+      acc4(va);
     }
     for (; r < r1; r += P) {
       const f16x8 v = *(const f16x8 *)(base + r * c);
@@ -190,11 +201,7 @@ __global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restri
   int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
   const f16 *xb = x + ((int64_t)inst * rows) * c + o * 8;
   f16 *yb = y + ((int64_t)inst * rows) * c + o * 8;
-  int64_t r = r0 + pr;
-  for (; r + 3 * (int64_t)P < r1; r += 4 * (int64_t)P) {     // four loads in flight per thread
-    f16x8 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *(const f16x8 *)(xb + (r + (int64_t)u * P) * c);
+  auto emit4 = [&](const f16x8 (&v)[4], int64_t rr) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       f16x8 w;
@@ -204,8 +211,26 @@ __global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restri
         if (silu) f = silu_f(f);
         w[e] = (f16)f;
       }
-      *(f16x8 *)(yb + (r + (int64_t)u * P) * c) = w;
+      *(f16x8 *)(yb + (rr + (int64_t)u * P) * c) = w;
     }
+  };
+  int64_t r = r0 + pr;
+  const int64_t step = 4 * (int64_t)P;
+  if (r + 3 * (int64_t)P < r1) {       // batches of four loads per thread, the next batch in flight while this one is written
+    f16x8 va[4], vb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) va[u] = *(const f16x8 *)(xb + (r + (int64_t)u * P) * c);
+    int64_t rp = r;
+    r += step;
+    for (; r + 3 * (int64_t)P < r1; r += step) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) vb[u] = *(const f16x8 *)(xb + (r + (int64_t)u * P) * c);
+      emit4(va, rp);
+      rp = r;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) va[u] = vb[u];
+    }
+    emit4(va, rp);
   }
   for (; r < r1; r += P) {
     const f16x8 v = *(const f16x8 *)(xb + r * c);
@@ -315,13 +340,18 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(const f16 *__restrict__ x
   }
 }
 
-int gn_splits(int instances, int64_t rows, int P) {
+// rows per statistics block: about 1024 blocks in all, >= 16 row-iterations per thread, at most 512 splits per instance
+// (sp_groupnorm_ws_bytes), and a multiple of 4*P rows so that the kernel runs whole batches of four loads per thread
+int64_t gn_rows_per_split(int instances, int64_t rows, int P) {
   int64_t want = (1024 + instances - 1) / instances;
-  int64_t maxs = rows / (16 * (int64_t)P); if (maxs < 1) maxs = 1;   // >= 16 row-iterations per thread
+  int64_t maxs = rows / (16 * (int64_t)P); if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
   if (want > 512) want = 512;
   if (want < 1) want = 1;
-  return (int)want;
+  const int64_t unit = 4 * (int64_t)P;
+  int64_t per = (rows + want - 1) / want;
+  per = (per + unit - 1) / unit * unit;
+  return per;
 }
 
 // ---------------------------------------------------------------------------------- LayerNorm
@@ -537,18 +567,20 @@ extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *
   const int P = gn_rows_per_iter(oc);
   const int threads = ((oc * P + 63) / 64) * 64 < 64 ? 64 : ((oc * P + 63) / 64) * 64;
   SP_REQUIRE(threads <= 1024, "sp_groupnorm_f16: C too large");
-  const int splits = gn_splits(instances, rows, P);
+  const int64_t per = gn_rows_per_split(instances, rows, P);
+  const int splits = (int)((rows + per - 1) / per);            // <= 512
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = ((size_t)P * c * 2 + (size_t)(threads / groups) * groups * 2) * sizeof(float);
   SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(gn_stats_kernel, dim3(instances, splits), dim3(threads), lds, s, (const f16 *)x,
-                     (float *)ws, rows, c, groups, splits);
+                     (float *)ws, rows, c, groups, splits, per);
   SP_CHECK_LAUNCH("sp_groupnorm_f16(stats)");
   int64_t blocks_y = (2048 + instances - 1) / instances;
   int64_t maxb = (rows + 16 * P - 1) / (16 * P);
   if (blocks_y > maxb) blocks_y = maxb;
   if (blocks_y < 1) blocks_y = 1;
-  const int64_t rpb = (rows + blocks_y - 1) / blocks_y;
+  int64_t rpb = (rows + blocks_y - 1) / blocks_y;
+  rpb = (rpb + 4 * P - 1) / (4 * P) * (4 * P);                 // whole batches of four loads per thread
   blocks_y = (rows + rpb - 1) / rpb;
   SP_CLEAR_STALE_ERROR();
   float *stats = (float *)ws + (size_t)instances * splits * groups * 2;
