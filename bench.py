@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" of this benchmark is ONE VIDEO: a synthetic 14-frame 576x1024 latent (1,4,14,72,128) fp16
-pushed through all 25 diffusion steps of the SVD UNet (random weights of the exact architecture, dummy
+pushed through all 25 diffusion steps of the SVD UNet; videos travel through the pipeline in micro-batches of two (one
+pipeline sample = latent (2,4,14,72,128): --micro-batch) (random weights of the exact architecture, dummy
 conditioning like the reference's ``set_dummy_conditioning``, no CFG = the reference benchmark default,
 ``/root/reference/src/modes/benchmark.py:60``).  With N > 1 the 25 steps are split into contiguous
 stages over the ranks (balanced split, e.g. [4,3,3,3,3,3,3,3]) and latents move stage-to-stage by RCCL
@@ -107,6 +108,10 @@ def parse():
     ap.add_argument("--concurrent", type=int, default=None,
                     help="videos kept in flight per GPU on separate HIP streams (1 = the reference's sequential "
                          "order; default 2)")
+    ap.add_argument("--micro-batch", type=int, default=None,
+                    help="videos per pipeline sample = batch dimension of every UNet call (default 2 when --steps is even: "
+                         "the 2,016- and 8,064-row levels fill the chip better, +3.5 %% videos/s measured; 1 = the "
+                         "reference benchmark's batch_size=1, ref src/modes/benchmark.py:101)")
     ap.add_argument("--no-rotate", action="store_true",
                     help="N>1: keep the extra step of the balanced split on the first ranks for every video "
                          "(default: rotate it with the video index so no stage is a permanent bottleneck)")
@@ -455,8 +460,16 @@ def main():
     conc = max(1, args.concurrent if args.concurrent is not None else 2)
     # N>1: 16N videos so that filling/draining the chain (N-1 stage times inside the bracketed region: the barriers on
     # both sides drain it) stays near 5 % (8N: 10 % at N = 8); ~20 s at every N
-    steps = args.steps if args.steps is not None else (4 * conc if n == 1 else max(16 * n, 2 * conc))
-    warmup = args.warmup if args.warmup is not None else (conc if n == 1 else max(n, conc))
+    steps = args.steps if args.steps is not None else (8 * conc if n == 1 else max(32 * n, 4 * conc))
+    warmup = args.warmup if args.warmup is not None else (2 * conc if n == 1 else max(2 * n, 2 * conc))
+    # micro-batch: `mb` videos travel together as ONE pipeline sample of shape (mb,4,F,H,W) (north_star: "micro-batched
+    # pipeline"); `steps` and `value` keep counting VIDEOS
+    mb = args.micro_batch if args.micro_batch is not None else (2 if steps % 2 == 0 else 1)
+    if mb < 1 or steps % mb:
+        raise SystemExit(f"bench.py: --steps {steps} videos is not a whole number of micro-batches of {mb}")
+    n_samples = steps // mb
+    warm_samples = -(-warmup // mb)
+    warmup = warm_samples * mb
 
     if shared:
         # rehearsal only (PIPELINE_BACKEND=gloo on a one-GPU box): ranks share the cards that exist; RCCL refuses this
@@ -491,10 +504,10 @@ def main():
     model = StableVideoUNet.from_random_init(StableVideoUNet._default_timestep_schedule(T), seed=0, device=device,
                                              fp8_attention=args.fp8_attention)
     torch.manual_seed(args.seed)  # same dummy conditioning on every rank
-    model.set_dummy_conditioning(1, args.frames, args.height, args.width, device,
+    model.set_dummy_conditioning(mb, args.frames, args.height, args.width, device,
                                  guidance_scale=args.guidance_scale)
     passes = 2 if (args.guidance_scale or 0) > 1.0 else 1
-    shape = torch.Size((1, 4, args.frames, args.height, args.width))
+    shape = torch.Size((mb, 4, args.frames, args.height, args.width))
     spec = LatentSpec(shape=shape, dtype=torch.float16, device=device)
     import logging
     quiet = logging.getLogger("bench.quiet"); quiet.setLevel(logging.ERROR)
@@ -551,7 +564,7 @@ def main():
     with torch.no_grad():
         if warmup > 0:
             dog.beat("warm-up")
-            stage.run_many(warmup, input_supplier=supplier if (rank == 0 or ring) else None)
+            stage.run_many(warm_samples, input_supplier=supplier if (rank == 0 or ring) else None)
             stage.drain()
         dog.beat("fence before the timed region")
         fence()
@@ -564,7 +577,7 @@ def main():
         stage.sample_done_hook = on_done
         t0 = time.perf_counter()
         start_ev = torch.cuda.Event(enable_timing=True); start_ev.record()
-        stage.run_many(steps, input_supplier=(lambda i: supplier(warmup + i)) if (rank == 0 or ring) else None)
+        stage.run_many(n_samples, input_supplier=(lambda i: supplier(warm_samples + i)) if (rank == 0 or ring) else None)
         stage.drain()
         dog.beat("fence after the timed region")
         fence()
@@ -588,7 +601,7 @@ def main():
         # completions arrive in groups of `conc` (videos interleaved on streams finish together): drop whole groups
         # covering the pipeline fill (N-1 samples) and rate the rest group-to-group.  Ring schedule: the last rank
         # finishes one video in N (those that started on rank 0), the others finish elsewhere at the same moments.
-        per_event = n if ring else 1
+        per_event = (n if ring else 1) * mb          # videos behind one completion event
         groups_dropped = 1 if ring else max(1, -(-(n - 1) // conc))
         d = groups_dropped * conc
         if len(times) - d >= 1 and times[-1] > times[d - 1]:
@@ -611,14 +624,14 @@ def main():
             "value": value, "unit": "videos/s", "n_gpus": n, "steps": steps, "warmup": warmup,
             "world_size_seen_by_process_group": dist.get_world_size() if n > 1 else 1,
             "backend": dist.get_backend() if n > 1 else "none", "ranks": ranks_seen, "rccl_env": rccl_env,
-            "gpus_shared_between_ranks": bool(shared and n > 1),
+            "gpus_shared_between_ranks": bool(shared and n > 1), "micro_batch": mb, "streams_per_gpu": conc,
             "peak_memory_gb_per_rank": [round(m, 3) for m in peaks], "max_peak_memory_gb": round(max(peaks), 3),
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f16+fp8 attention" if args.fp8_attention else "f16", "data": "synthetic",
             "config": {"workload": f"SVD img2vid UNet (1.52B params, random init), latent (1,4,{args.frames},"
                                    f"{args.height},{args.width}) fp16, {T} steps, {passes} UNet pass/step "
-                                   f"(guidance_scale={args.guidance_scale}), {conc} videos in flight per GPU "
-                                   f"on separate HIP streams"
+                                   f"(guidance_scale={args.guidance_scale}), micro-batches of {mb} video(s) per UNet "
+                                   f"call, {conc} micro-batches in flight per GPU on separate HIP streams"
                                    + (", spatial attention on fp8-e4m3 MFMA" if args.fp8_attention else ""),
                        "stage_steps": stage_sizes(T, n, balanced=True),
                        "stage_steps_rotate_with_video_index": bool(rotating),

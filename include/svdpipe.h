@@ -96,7 +96,7 @@ typedef struct sp_gemm_desc {
   float euler_sigma, euler_sigma_next;
   int euler_frames; int64_t euler_hw;                  /* m = b*frames*hw + f*hw + pixel */
   /* Optional scratch (the library never allocates): with at least sp_gemm_workspace_bytes(desc) bytes, contractions with
-     few rows and a long K (m <= 2560, K >= 8192: the 3x3 convolutions of the UNet's 2,016-row level) are split over K on 256 x 256 tiles,
+     few rows and a long K (m <= 6144, K >= 8192: the 3x3 convolutions of the UNet's 2,016-row level, 4,032 rows for a micro-batch of two) are split over K on 256 x 256 tiles,
      fp32 partial sums go here and a second kernel reduces them and applies the epilogue.  NULL = never split. */
   void *workspace; size_t workspace_bytes;
 } sp_gemm_desc;

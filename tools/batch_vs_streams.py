@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 model = StableVideoUNet.from_random_init(StableVideoUNet._default_timestep_schedule(25), seed=0, device=dev)
 steps = 6
 ALL = [torch.cuda.Stream() for _ in range(4)]
-for B, S in ((1, 1), (1, 2), (1, 3), (2, 1), (2, 2), (1, 2), (1, 1)):
+for B, S in [tuple(map(int, a.split("x"))) for a in os.environ.get("ARMS", "1x1,1x2,1x3,2x1,2x2,1x2,1x1").split(",")]:
     torch.manual_seed(42)
     model.set_dummy_conditioning(B, 14, 72, 128, dev)
     lats = [torch.randn(B, 4, 14, 72, 128, device=dev, dtype=torch.float16) * model.init_noise_sigma for _ in range(S)]

@@ -10,7 +10,7 @@ import vdpp_amd  # noqa
 from vdpp_amd.hip import ops
 
 ARMS = [("auto", (0, 0, 0)), ("pp", (2, 0, 0)), ("ps256", (3, 256, 0)), ("ps192", (3, 192, 0)), ("ps128x320", (3, 128, 320))]
-SPLITK_ARMS = [("small", (1, 0, 0)), ("128x64", (1, 128, 0)), ("split-K", (4, 0, 0)), ("auto+ws", (0, 0, 0))]   # m <= 2560
+SPLITK_ARMS = [("small", (1, 0, 0)), ("128x64", (1, 128, 0)), ("split-K", (4, 0, 0)), ("auto+ws", (0, 0, 0))]   # m <= 6144
 
 
 def run(spec, iters=20, rounds=4):
@@ -23,10 +23,12 @@ def run(spec, iters=20, rounds=4):
     conv = temporal = None
     if mode == 1:
         h, w = 72, 128
-        while 14 * h * w > m: h //= 2; w //= 2
-        conv = (14, h, w, h, w, 1, 0)
+        nimg = 14
+        while nimg * h * w > m and h > 9: h //= 2; w //= 2
+        while nimg * h * w < m: nimg += 14                # micro-batches: more images of the smallest level
+        conv = (nimg, h, w, h, w, 1, 0)
     if mode == 2:
-        temporal = (14, m // 14)
+        temporal = (14, m // 14) if m <= 129024 else (14, 129024 // 14)
     a = torch.randn(m, cin, device=dev, dtype=torch.float16)
     wt = torch.randn(n, taps * cin, device=dev, dtype=torch.float16) * 0.02
     no = n // 2 if geglu else n
@@ -38,7 +40,7 @@ def run(spec, iters=20, rounds=4):
     if "r2" in flags:
         kw.update(res2=torch.randn(m, no, device=dev, dtype=torch.float16), r2scale=0.5)
     arms = ARMS
-    if m <= 2560:
+    if m <= 6144:
         arms = SPLITK_ARMS
         need = ops.gemm_workspace_bytes(m=m, n=n, cin=cin, mode=mode)
         if need: kw.update(workspace=torch.empty(need, dtype=torch.uint8, device=dev))

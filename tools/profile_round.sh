@@ -1,6 +1,7 @@
 #!/bin/bash
 # The round's committed profile set (run on the GPU box): usage: tools/profile_round.sh <tag> <commit>
-#   gpurun_out/<tag>_b_serial_stats.csv / _c_2streams_stats.csv : rocprofv3 --kernel-trace --stats of one / two videos
+#   gpurun_out/<tag>_b_serial_stats.csv / _c_2streams_stats.csv : rocprofv3 --kernel-trace --stats of one / two micro-batches
+#                                                                   of two videos (25 / 50 UNet forwards at batch 2)
 #   gpurun_out/<tag>_a_pmc.txt + <tag>_pmc_traffic.json          : the three --pmc passes folded per kernel
 #   gpurun_out/<tag>_bench.json                                   : the default bench line (per_template FLOPs)
 #   gpurun_out/<tag>_per_template.txt                             : fraction of peak per kernel template
@@ -8,11 +9,11 @@ set -e
 TAG=$1; COMMIT=$2
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_ps -- python3 $R/bench.py --concurrent 1 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-decode > $R/gpurun_out/${TAG}_b_serial.json 2> $R/gpurun_out/${TAG}_b_serial.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_ps -- python3 $R/bench.py --concurrent 1 --steps 2 --warmup 0 --no-cpu-baseline --no-roofline --no-decode > $R/gpurun_out/${TAG}_b_serial.json 2> $R/gpurun_out/${TAG}_b_serial.err
 cp $(find $R/gpurun_out/${TAG}_ps -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_b_serial_stats.csv
 rm -rf $R/gpurun_out/${TAG}_ps
 echo serial done
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_p2 -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-roofline --no-decode > $R/gpurun_out/${TAG}_c_2streams.json 2> $R/gpurun_out/${TAG}_c_2streams.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_p2 -- python3 $R/bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-roofline --no-decode > $R/gpurun_out/${TAG}_c_2streams.json 2> $R/gpurun_out/${TAG}_c_2streams.err
 cp $(find $R/gpurun_out/${TAG}_p2 -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_c_2streams_stats.csv
 rm -rf $R/gpurun_out/${TAG}_p2
 echo two-streams done

@@ -461,9 +461,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
   }
 }
 
-// split-K plan for few-row contractions: number of K slices (0 = do not split) for 256 x 256 tiles
+// split-K plan for few-row contractions: number of K slices (0 = do not split) for 256 x 256 tiles.  Up to 6,144 rows
+// (24 x 5 tiles at 1,280 columns still leave half the chip idle): the 2,016-row level of one video and the 4,032-row
+// level of a micro-batch of two.
+constexpr int SPLITK_MAX_ROWS = 6144;
 int splitk_slices(const sp_gemm_desc *d, int taps, bool forced) {
-  if (d->n % 256 || d->m > 2560 || d->euler_out) return 0;
+  if (d->n % 256 || d->m > SPLITK_MAX_ROWS || d->euler_out) return 0;
   const int nk = taps * d->cin / 32;
   // K >= 8192 (the 3x3 convolutions over 1280 / 2560 channels: 100 -> 74 us, 203 -> 120 us).  Slab writes + the reduce
   // kernel cost ~20 us per call, which at K = 3840 / 5120 / 5760 (temporal convolution, FF2, 640-channel 3x3) is what
@@ -539,6 +542,12 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
     if (route == 1 && g_route_bm == 128) return launch<128, 64, 2, 2, 2>(a, s);     // (micro-benchmarks)
     return launch<64, 64, 2, 2, 3>(a, s);
   }
+  // ---- a few thousand rows (the 4,032-row level of a micro-batch of two): where the large tiles would leave more than
+  // a third of the CUs without a workgroup, 128 x 128 tiles (two workgroups per CU) win: measured at 4,032 x 1,280:
+  // (3,1,1) convolution 54.5 vs 67.2 us, linear + residual 26.8 vs 31.1, FF2 (K = 5,120) 72.6 vs 91.3
+  if (route == 0 && d->m <= SPLITK_MAX_ROWS && n128 && ok256 &&
+      ((d->m + 191) / 192) * (d->n / 256) < 160)
+    return launch<128, 128, 2, 2, 2>(a, s);
   // ---- large ping-pong tiles (gemm_pp.hip) for every N that is a multiple of 256 or 320
   if (route != 1 && (ok256 || ok320)) {
     // Pick the (BM, BN) whose last round of workgroups wastes the fewest of the 256 CUs (one workgroup per CU);

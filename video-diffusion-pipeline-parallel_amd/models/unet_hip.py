@@ -125,6 +125,8 @@ class SVDUNetHIP:
     # fp8 attention pays a quantise pass over q/k/v: below ~1k tokens per frame (the 576- and 144-token levels) the
     # fp16 kernel is faster (tools/bench_attn.py: 46 vs 56 us at 576 tokens, 1907 vs 1580 us at 9216)
     FP8_MIN_SEQ = 1024
+    # few-row levels whose long-K contractions may be split over K (csrc/gemm.hip::SPLITK_MAX_ROWS)
+    SPLITK_MAX_ROWS = 6144
 
     def __init__(self, cfg: UNetConfig, state_dict: dict, device, *, fp8_attention: bool | None = None):
         """``fp8_attention``: run the spatial self-attention on fp8-e4m3 MFMA (BASELINE config 5: "SVD-XT ... with
@@ -327,7 +329,7 @@ class SVDUNetHIP:
             raise RuntimeError("this contraction carries a folded LayerNorm: pass ln_stats")
         ops.gemm(a, layer.w, out, m=m, n=layer.n, cin=layer.cin, mode=layer.mode, conv=conv, temporal=temporal,
                  bias=layer.bias, geglu=layer.geglu, n_store=n_store, ldd=layer.n_true, lda=a.shape[1],
-                 ln_colsum=layer.colsum, workspace=r.sk_ws if m <= 2560 else None, **kw)
+                 ln_colsum=layer.colsum, workspace=r.sk_ws if m <= self.SPLITK_MAX_ROWS else None, **kw)
         return out
 
     def _ln_stats(self, layer: _Dense, x, **kw):
@@ -447,11 +449,11 @@ class SVDUNetHIP:
         if gn_ws is None or gn_ws.numel() < ws_bytes:
             gn_ws = self._gn_ws[skey] = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
 
-        # split-K scratch for the levels with at most 2,560 rows (up to 8 fp32 slabs of rows x channels), per stream as well
+        # split-K scratch for the levels with at most SPLITK_MAX_ROWS rows (up to 8 fp32 slabs of rows x channels), per stream
         sk_bytes = 0
         for lvl, c in enumerate(cfg.block_out_channels):
             rows = b * frames * (h >> min(lvl, 3)) * (w >> min(lvl, 3))
-            if rows <= 2560:
+            if rows <= self.SPLITK_MAX_ROWS:
                 sk_bytes = max(sk_bytes, 8 * rows * c * 4)
         sk_ws = self._sk_ws.get(skey)
         if sk_bytes and (sk_ws is None or sk_ws.numel() < sk_bytes):
