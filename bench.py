@@ -457,16 +457,26 @@ def main():
         raise SystemExit(f"bench.py: --gpus {world} but torch sees {have} device(s); refusing to run (rehearsal on fewer "
                          f"cards: VDPP_SHARE_GPU=1 PIPELINE_BACKEND=gloo)")
     n = world
-    conc = max(1, args.concurrent if args.concurrent is not None else 2)
-    # N>1: 16N videos so that filling/draining the chain (N-1 stage times inside the bracketed region: the barriers on
-    # both sides drain it) stays near 5 % (8N: 10 % at N = 8); ~20 s at every N
-    steps = args.steps if args.steps is not None else (8 * conc if n == 1 else max(32 * n, 4 * conc))
-    warmup = args.warmup if args.warmup is not None else (2 * conc if n == 1 else max(2 * n, 2 * conc))
-    # micro-batch: `mb` videos travel together as ONE pipeline sample of shape (mb,4,F,H,W) (north_star: "micro-batched
-    # pipeline"); `steps` and `value` keep counting VIDEOS
-    mb = args.micro_batch if args.micro_batch is not None else (2 if steps % 2 == 0 else 1)
+    # N>1: 32N videos so that filling/draining the chain (N-1 stage times inside the bracketed region: the barriers on
+    # both sides drain it) stays near 5-10 %; ~20-40 s at every N
+    steps = args.steps if args.steps is not None else (16 if n == 1 else 32 * n)
+    # How many videos a GPU keeps in flight: `mb` videos travel together as ONE pipeline sample of shape (mb,4,F,H,W)
+    # (north_star: "micro-batched pipeline"), `conc` samples are interleaved on separate HIP streams.  More in flight
+    # raises the rate of a busy stage (measured ms per video and UNet forward on one MI355X: 52.3 at 1 x 1, 49.4 at
+    # 1 x 2 streams, 49.8 at batch 2 x 1, 47.5 at 2 x 2) but lengthens the chain's fill and drain, which matters when
+    # the job is short for its N: pick the pair with the smallest predicted time (groups + N - 1) x group time.
+    # `steps` and `value` keep counting VIDEOS.
+    MS = {(1, 1): 52.3, (1, 2): 49.4, (2, 1): 49.8, (2, 2): 47.5}
+    cands = [(b_, c_) for (b_, c_) in MS if steps % b_ == 0
+             and (args.micro_batch is None or args.micro_batch == b_) and (args.concurrent is None or args.concurrent == c_)]
+    if cands:
+        mb, conc = min(cands, key=lambda bc: (steps / (bc[0] * bc[1]) + n - 1) * bc[0] * bc[1] * MS[bc])
+    else:       # explicit values outside the table
+        mb = args.micro_batch if args.micro_batch is not None else 1
+        conc = max(1, args.concurrent if args.concurrent is not None else 2)
     if mb < 1 or steps % mb:
         raise SystemExit(f"bench.py: --steps {steps} videos is not a whole number of micro-batches of {mb}")
+    warmup = args.warmup if args.warmup is not None else (2 * mb * conc if n == 1 else max(2 * n, 2 * mb * conc))
     n_samples = steps // mb
     warm_samples = -(-warmup // mb)
     warmup = warm_samples * mb

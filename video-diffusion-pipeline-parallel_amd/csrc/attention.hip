@@ -162,9 +162,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
     // ---- S^T = K.Q^T - m : two 32-key sub-tiles, accumulators start at minus the running maximum
     f32x16 sacc[2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int s = 0; s < 4; ++s) {      // k-step-major: both chains take -m as their C operand with a fresh destination
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int kt = 0; kt < 2; ++kt) {
         const f16x8 kf = *(const f16x8 *)(sk + koff[kt] + (((2 * s + h) ^ kswz) << 4));
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], s == 0 ? negm : sacc[kt], 0, 0, 0);
       }
