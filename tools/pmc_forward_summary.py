@@ -63,6 +63,7 @@ if len(sys.argv) > 2:
                          "passes over the two UNet forwards of tools/one_forward.py = second half of the dispatches)",
                "kernel": "implicit-GEMM kernels (gemm_pp_kernel<*>, gemm_ps_kernel<*>, gemm_f16_kernel<*>)",
                "commit": sys.argv[3] if len(sys.argv) > 3 else "unknown",
+               "micro_batch": int(__import__("os").environ.get("BATCH", 2)),      # videos per UNet call in tools/one_forward.py
                "fabric_read_bytes": rd, "write_bytes": wr, "launches": int(n),
                "note": "read bytes = 2 x FETCH_SIZE (gfx950 half-count correction, calibrated on this kernel family's access "
                        "shapes: profiles/r03_fetch_size_calibration.txt), Infinity-Cache hits included"},

@@ -169,6 +169,9 @@ class StableVideoUNet(nn.Module):
         if not enabled:
             self._graphs.clear()
             self._graph_lanes.clear()
+            release = getattr(self.unet, "release_stream_state", None)
+            if release is not None:
+                release()
 
     def enable_memory_optimizations(self) -> None:
         """Kept for API compatibility (ref ``svd_unet.py:166-194``); nothing to toggle here."""
@@ -241,6 +244,10 @@ class StableVideoUNet(nn.Module):
         self._guidance_scale_tensor = None
         self._guidance32 = None
         self._graphs.clear()
+        self._graph_lanes.clear()            # capture streams / pools are keyed by the calling stream's raw handle
+        release = getattr(self.unet, "release_stream_state", None)
+        if release is not None:
+            release()
 
     # ------------------------------------------------------------------ one diffusion step
     def _unet_pass(self, latent, image_latents, embeddings, in_scale, step, euler=None):

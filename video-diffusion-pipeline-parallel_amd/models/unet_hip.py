@@ -192,6 +192,16 @@ class SVDUNetHIP:
         self._pos_cache = {}
         self._fp8_ws = {}
 
+    def release_stream_state(self) -> None:
+        """Drop every per-stream scratch buffer (GroupNorm partials, split-K slabs, fp8 operands).  They are keyed by
+        the raw handle of the HIP stream a forward ran on, and a destroyed stream's handle can be handed out again: a
+        caller that creates streams per run calls this when it retires them (``StableVideoUNet.clear_conditioning`` and
+        ``enable_graphs(False)`` do), otherwise the streams must outlive the model.  The next forward on any stream
+        simply allocates again."""
+        self._gn_ws = None
+        self._sk_ws = {}
+        self._fp8_ws = {}
+
     # ------------------------------------------------------------------ weight packing
     def _reg_temb(self, sd, p):
         w = W.pack_linear(sd[p + ".weight"]).to(self.device)
