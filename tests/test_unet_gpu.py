@@ -363,12 +363,13 @@ class _FakeWork:
         return True
 
 
-@pytest.mark.parametrize("conc,rotate", [(1, False), (2, False), (3, False), (2, True)])
-def test_side_stream_link_with_emulated_stream_ordered_p2p(monkeypatch, conc, rotate):
+@pytest.mark.parametrize("conc,rotate,mb", [(1, False, 1), (2, False, 1), (3, False, 1), (2, True, 1), (2, True, 2), (1, False, 2)])
+def test_side_stream_link_with_emulated_stream_ordered_p2p(monkeypatch, conc, rotate, mb):
     """Two pipeline ranks emulated in ONE process on one GPU: torch.distributed isend/irecv are replaced by
     stream-ordered mailbox copies (what RCCL P2P provides: the transfer is ordered after the work already enqueued
     on the issuing stream).  Exercises _SideStreamLink (events, fresh receive buffers, record_stream) and the
-    interleaved scheduler exactly as the RCCL path does, and checks the 2-rank result == the 1-rank result."""
+    interleaved scheduler exactly as the RCCL path does, and checks the 2-rank result == the 1-rank result.
+    mb = 2: every pipeline sample is a micro-batch of two videos (bench.py's default), latent (2,4,F,H,W)."""
     import vdpp_amd.pipeline.pipeline as pl
     from vdpp_amd.models.svd_unet import StableVideoUNet
     from vdpp_amd.pipeline import LatentSpec, PipelineConfig, PipelineStage
@@ -396,8 +397,8 @@ def test_side_stream_link_with_emulated_stream_ordered_p2p(monkeypatch, conc, ro
     steps = 5
     model = StableVideoUNet(unet=hip, timesteps=StableVideoUNet._default_timestep_schedule(steps))
     torch.manual_seed(8)
-    model.set_dummy_conditioning(1, 3, 8, 16, torch.device(DEV))
-    shape = torch.Size((1, 4, 3, 8, 16))
+    model.set_dummy_conditioning(mb, 3, 8, 16, torch.device(DEV))
+    shape = torch.Size((mb, 4, 3, 8, 16))
     spec = LatentSpec(shape=shape, dtype=torch.float16, device=torch.device(DEV))
     xs = [(torch.randn(shape) * 20).half().to(DEV) for _ in range(5)]
 
