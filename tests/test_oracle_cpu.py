@@ -131,3 +131,70 @@ def test_schedule_matches_diffusers_fixture(golden_dir):
         assert np.allclose(s, z[f"sigmas.{n}"], rtol=1e-6, atol=1e-7)
         assert np.allclose(euler_sched.continuous_timesteps(s), z[f"timesteps.{n}"], rtol=1e-6, atol=1e-6)
         assert abs(euler_sched.init_noise_sigma(s) - float(z[f"init_noise_sigma.{n}"])) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ edge stages (round 3)
+def test_vae_oracle_matches_the_published_architecture_and_the_engine_inventory():
+    """The VAE oracle and the HIP engine's parameter inventory describe the same network: diffusers key names load
+    strict, and the sizes are the published ones (decoder 63,579,183 + encoder / quant_conv 34,163,664 = 97,742,847)."""
+    from oracle.vae_temporal_decoder_ref import EncoderRef, TemporalDecoderRef, VAEDecoderConfig as RefCfg
+    from vdpp_amd.models import vae_hip
+
+    cfg = vae_hip.VAEDecoderConfig.svd()
+    dec_sd = {k: torch.empty(s) for k, s, _ in vae_hip.param_inventory(cfg)}
+    enc_sd = {k: torch.empty(s) for k, s, _ in vae_hip.encoder_param_inventory(cfg)}
+    with torch.device("meta"):
+        dec, enc = TemporalDecoderRef(RefCfg.svd()), EncoderRef(RefCfg.svd())
+    assert {k: tuple(v.shape) for k, v in dec.state_dict().items()} == {k: tuple(v.shape) for k, v in dec_sd.items()}
+    assert {k: tuple(v.shape) for k, v in enc.state_dict().items()} == {k: tuple(v.shape) for k, v in enc_sd.items()}
+    assert vae_hip.param_count(cfg) == 63_579_183
+    assert sum(v.numel() for v in enc_sd.values()) == 34_163_664
+
+
+def test_vae_oracle_chunked_decode_and_encode_shapes():
+    """decode_latents cuts the flattened (batch, frame) list into chunks (ref generate_video_demo.py:177-183): a chunk
+    size that divides F gives per-video temporal context, the result differs from one-call decoding only through the
+    temporal layers; encode repeats ONE image latent over the frames."""
+    from oracle.vae_temporal_decoder_ref import (EncoderRef, TemporalDecoderRef, VAEDecoderConfig, decode_latents,
+                                                 decoder_flops, encode_image_latents)
+    torch.manual_seed(0)
+    cfg = VAEDecoderConfig.tiny(32)
+    cfg.norm_groups = 8
+    dec, enc = TemporalDecoderRef(cfg).eval(), EncoderRef(cfg).eval()
+    lat = torch.randn(1, 4, 4, 4, 4)
+    full = decode_latents(lat, dec, 4, decode_chunk_size=14)
+    halves = decode_latents(lat, dec, 4, decode_chunk_size=2)
+    assert full.shape == halves.shape == (1, 3, 4, 32, 32) and full.dtype == torch.float32
+    with torch.no_grad():
+        direct = dec(lat.permute(0, 2, 1, 3, 4).flatten(0, 1)[:2] / cfg.scaling_factor, 2)
+    assert torch.allclose(halves[0, :, :2].permute(1, 0, 2, 3), direct, atol=1e-5)
+    assert not torch.allclose(full, halves, atol=1e-4)              # frames 1|2 see each other only in one call
+    img = torch.randn(2, 3, 32, 32)
+    out = encode_image_latents(img, enc, 5)
+    assert out.shape == (2, 4, 5, 4, 4) and torch.equal(out[:, :, 0], out[:, :, 4])
+    assert abs(decoder_flops(VAEDecoderConfig.svd(), 14, 72, 128) / 1e12 - 97.2) < 0.1
+
+
+def test_clip_spec_is_the_svd_image_encoder():
+    from transformers import CLIPVisionConfig
+    from vdpp_amd.models.clip_hip import CLIPVisionSpec
+    s = CLIPVisionSpec.svd()
+    got = (s.hidden_size, s.num_hidden_layers, s.num_attention_heads, s.patch_size, s.image_size, s.projection_dim)
+    assert got == (1280, 32, 16, 14, 224, 1024)
+    cfg = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                           image_size=28, patch_size=14, projection_dim=64, hidden_act="quick_gelu")
+    assert CLIPVisionSpec.from_config(cfg) == CLIPVisionSpec(128, 256, 2, 2, 28, 14, 64, cfg.layer_norm_eps, "quick_gelu")
+
+
+def test_edge_engines_refuse_to_run_without_a_hip_device():
+    """No CPU fallback anywhere on the product path: constructing an engine on the CPU fails loudly."""
+    import pytest
+    from vdpp_amd.models import vae_hip
+    from vdpp_amd.models.clip_hip import CLIPVisionHIP, CLIPVisionSpec
+    cfg = vae_hip.VAEDecoderConfig.tiny(64)
+    with pytest.raises(RuntimeError):
+        vae_hip.TemporalDecoderHIP(cfg, {}, "cpu")
+    with pytest.raises(RuntimeError):
+        vae_hip.ImageEncoderHIP(cfg, {}, "cpu")
+    with pytest.raises(RuntimeError):
+        CLIPVisionHIP(CLIPVisionSpec.svd(), {}, "cpu")
