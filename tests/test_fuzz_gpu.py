@@ -29,9 +29,10 @@ def test_gemm_fuzz(route, bm):
 
 def test_attention_and_norm_fuzz():
     """tools/fuzz_misc.py: random shapes of the spatial (fp16 and fp8) / temporal attention, GroupNorm (three-launch
-    and single-launch paths) and LayerNorm kernels against fp32 torch, with guard rows around every output.
+    and single-launch paths), LayerNorm, and (round 3) the CLIP small-sequence attention, the VAE row softmax and GELU
+    kernels against fp32 torch, with guard rows around every output.
     Tolerances: 3e-3 relative L2 (fp16 kernels), 3e-2 for the fp8 attention against the e4m3-rounded inputs."""
     import fuzz_misc
     rng, g = random.Random(77), torch.Generator().manual_seed(77)
-    for _ in range(60):
+    for _ in range(90):
         fuzz_misc.one(rng, g)

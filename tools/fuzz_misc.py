@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised cross-checks of the attention, normalisation, LayerNorm-statistics and GEMV kernels against fp32 / fp64
-torch (CPU), with guard rows around every output (no write outside the rows the call owns).
+"""Randomised cross-checks of the attention (UNet, CLIP), normalisation, LayerNorm-statistics, GEMV, row-softmax and GELU
+kernels against fp32 / fp64 torch (CPU), with guard rows around every output (no write outside the rows the call owns).
 usage: fuzz_misc.py [cases] [seed]"""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -167,8 +167,68 @@ def gemv(rng, g):
     return e
 
 
+def attn_small(rng, g):
+    """CLIP-style attention: short sequences, any head width that is a multiple of 8 (K, V of a head must fit in LDS)."""
+    import math
+    batch, heads = rng.choice([1, 2, 3]), rng.choice([1, 2, 5, 16])
+    hd = rng.choice([8, 40, 64, 80, 128])
+    seq = rng.choice([1, 2, 63, 64, 65, 200, 257, 300])
+    if seq * (hd + 1) * 4 > 140 * 1024:
+        seq = 130
+    c = heads * hd
+    qkv = h(torch.randn(batch * seq, 3 * c, generator=g) * rng.choice([0.5, 1.0, 2.0]))
+    d = qkv.half().to(DEV)
+    buf, o = guarded(batch * seq, c)
+    ops.attn_small(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=batch, seq=seq,
+                   heads=heads, head_dim=hd, scale=1.0 / math.sqrt(hd))
+    torch.cuda.synchronize()
+    q, k, v = [t.reshape(batch, seq, heads, hd).transpose(1, 2) for t in qkv.split(c, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(batch * seq, c)
+    what = f"attn_small batch={batch} seq={seq} heads={heads} hd={hd}"
+    e = rel_l2(check_guard(buf, batch * seq, what), ref)
+    assert e <= 2e-3, f"rel_l2={e:.3e}: {what}"
+    return e
+
+
+def softmax_rows(rng, g):
+    """The VAE mid block's in-place row softmax: any column count that is a multiple of 8 up to 16,384, row pitch >= it."""
+    rows = rng.choice([1, 3, 64, 257])
+    cols = rng.choice([8, 64, 264, 2048, 2056, 4104, 9216, 16384])
+    ld = cols + rng.choice([0, 8, 64])
+    x = h(torch.randn(rows, ld, generator=g) * rng.choice([0.5, 4.0, 30.0]))
+    buf = torch.full((rows + 2 * G, ld), 9.0, dtype=torch.float16, device=DEV)
+    buf[G:G + rows] = x.half().to(DEV)
+    ops.softmax_rows(buf[G:G + rows], rows=rows, cols=cols, ld=ld)
+    torch.cuda.synchronize()
+    what = f"softmax_rows rows={rows} cols={cols} ld={ld}"
+    got = check_guard(buf, rows, what)
+    assert torch.equal(got[:, cols:], x[:, cols:]), "columns past cols touched: " + what
+    ref = torch.softmax(x[:, :cols], dim=-1)
+    assert float((got[:, :cols] - ref).abs().max()) <= 2e-3, what
+    e = rel_l2(got[:, :cols], ref)
+    assert e <= 2e-3, f"rel_l2={e:.3e}: {what}"
+    return e
+
+
+def gelu(rng, g):
+    n = 8 * rng.choice([1, 37, 4096, 40001])
+    x = h(torch.randn(n, generator=g) * rng.choice([0.5, 3.0, 8.0]))
+    quick = rng.random() < 0.5
+    buf = torch.full((n + 16,), 9.0, dtype=torch.float16, device=DEV)
+    ops.gelu(x.half().to(DEV), buf[8:8 + n], quick=quick)
+    torch.cuda.synchronize()
+    got = buf.float().cpu()
+    assert torch.all(got[:8] == 9.0) and torch.all(got[8 + n:] == 9.0), "gelu guard"
+    ref = x * torch.sigmoid(1.702 * x) if quick else F.gelu(x)
+    assert float((got[8:8 + n] - ref).abs().max()) <= 8e-3 and rel_l2(got[8:8 + n], ref) <= 1e-3, f"gelu n={n} quick={quick}"
+    return 0.0
+
+
 def one(rng, g):
-    kind = rng.choice(["as", "as", "as8", "at", "gn", "gn", "ln", "lns", "lns", "gv"])
+    kind = rng.choice(["as", "as", "as8", "at", "gn", "gn", "ln", "lns", "lns", "gv", "asm", "asm", "sm", "gl"])
+    if kind == "asm": return attn_small(rng, g)
+    if kind == "sm": return softmax_rows(rng, g)
+    if kind == "gl": return gelu(rng, g)
     if kind == "lns": return ln_stats(rng, g)
     if kind == "gv": return gemv(rng, g)
     if kind == "as": return attn_spatial(rng, g, False)
