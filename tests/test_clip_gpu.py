@@ -85,6 +85,24 @@ def _pair(cfg):
     return CLIPVisionHIP(CLIPVisionSpec.from_config(cfg), sd, DEV), ref
 
 
+def test_clip_matches_committed_golden_vector(golden_dir):
+    """HIP engine vs tests/golden/clip_tiny.npz (weights, pixel_values and image_embeds minted by transformers itself,
+    tests/golden/make_clip_golden.py): no third-party code involved at test time."""
+    import os
+    import numpy as np
+    from tests.golden.make_clip_golden import CFG
+    from vdpp_amd.models.clip_hip import CLIPVisionHIP, CLIPVisionSpec
+
+    z = np.load(os.path.join(golden_dir, "clip_tiny.npz"))
+    spec = CLIPVisionSpec(CFG["hidden_size"], CFG["intermediate_size"], CFG["num_hidden_layers"], CFG["num_attention_heads"],
+                          CFG["image_size"], CFG["patch_size"], CFG["projection_dim"], CFG["layer_norm_eps"], CFG["hidden_act"])
+    sd = {k[2:]: torch.from_numpy(z[k]).half() for k in z.files if k.startswith("w:")}
+    hip = CLIPVisionHIP(spec, sd, DEV)
+    got = hip(torch.from_numpy(z["pixel_values"]).half().to(DEV))
+    torch.cuda.synchronize()
+    assert rel_l2(got.float().cpu(), torch.from_numpy(z["image_embeds"])) <= 1e-2
+
+
 def test_clip_small_config_matches_transformers():
     from transformers import CLIPVisionConfig
     cfg = CLIPVisionConfig(hidden_size=128, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2, image_size=56,

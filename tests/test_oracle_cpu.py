@@ -198,3 +198,20 @@ def test_edge_engines_refuse_to_run_without_a_hip_device():
         vae_hip.ImageEncoderHIP(cfg, {}, "cpu")
     with pytest.raises(RuntimeError):
         CLIPVisionHIP(CLIPVisionSpec.svd(), {}, "cpu")
+
+
+def test_clip_golden_vector_still_matches_transformers(golden_dir):
+    """tests/golden/clip_tiny.npz was minted by transformers' CLIPVisionModelWithProjection (make_clip_golden.py): the
+    installed transformers must still reproduce it (a version drift of the dependency shows here, not on the GPU)."""
+    import os
+    import numpy as np
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from tests.golden.make_clip_golden import CFG
+
+    z = np.load(os.path.join(golden_dir, "clip_tiny.npz"))
+    model = CLIPVisionModelWithProjection(CLIPVisionConfig(**CFG)).eval()
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}, strict=True)
+    with torch.no_grad():
+        out = model(torch.from_numpy(z["pixel_values"]))
+    assert torch.allclose(out.image_embeds, torch.from_numpy(z["image_embeds"]), atol=2e-5, rtol=1e-4)
+    assert torch.allclose(out.last_hidden_state, torch.from_numpy(z["last_hidden_state"]), atol=2e-4, rtol=1e-4)
