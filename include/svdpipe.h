@@ -173,6 +173,19 @@ int sp_attn_spatial_f16(const void *q, const void *k, const void *v, void *o, in
 int sp_attn_temporal_f16(const void *q, const void *k, const void *v, void *o, int64_t ldq,
                          int64_t ldk, int64_t ldv, int64_t ldo, int batch, int frames, int64_t hw,
                          int heads, float scale, const void *zero_page, void *stream);
+/* sp_attn_spatial_f16 for LONG rows (csrc/attention_long.hip): same arguments, same results to fp16 rounding.
+ * One wave per SIMD with two query blocks; after a warm-up over the workgroup's own tokens and tile 0 (ordinary
+ * online softmax) each row's reference is frozen at the maximum seen so far and the remaining K/V tiles run without
+ * row maximum or rescale.  A later score more than 16 (log2 units) above that reference overflows fp16, is detected
+ * through the row sum, and the 256-row block is recomputed by sp_attn_spatial_f16's kernel inside the same call, so
+ * accuracy never depends on the data (only the time does).  Applies to seq >= 4096 with seq % 256 == 0; every other
+ * shape is passed to sp_attn_spatial_f16's kernel unchanged (workspace unused).  workspace: >=
+ * sp_attn_long_ws_bytes(batch, seq, heads) bytes, 4-byte aligned, owned by the caller and private to the call until
+ * it has completed on `stream` (one flag word per 256 query rows; zeroed by the call). */
+int64_t sp_attn_long_ws_bytes(int batch, int seq, int heads);
+int sp_attn_spatial_long_f16(const void *q, const void *k, const void *v, void *o, int64_t ldq, int64_t ldk,
+                             int64_t ldv, int64_t ldo, int batch, int seq, int heads, float scale,
+                             const void *zero_page, void *workspace, int64_t workspace_bytes, void *stream);
 /* fp8 (OCP e4m3fn) MFMA variant of sp_attn_spatial_f16 for BASELINE config 5 ("fp8 MFMA attention path"; the
  * reference has no fp8 path of its own, its attention is diffusers/xformers behind svd_unet.py:142-199).
  * Same arguments and fp16 inputs/outputs; q/k/v are quantised per call into `workspace` (Q8, K8 row-major,

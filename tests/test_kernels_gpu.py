@@ -496,6 +496,112 @@ def test_attention_spatial_long_rows(batch, seq, heads):
     check(o, ref, l2=3e-3, mx=2e-2)
 
 
+def _attn_long(ops, d, c, batch, seq, heads, ws=None):
+    o = torch.empty(batch * seq, c, dtype=torch.float16, device=DEV)
+    if ws is None:
+        ws = torch.full((ops.attn_long_ws_bytes(batch, seq, heads) // 4,), 0x7fffffff, dtype=torch.int32, device=DEV)  # stale junk
+    ops.attn_spatial_long(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o, ws, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c,
+                          batch=batch, seq=seq, heads=heads)
+    return o, ws
+
+
+def _sdpa(qkv, c, batch, seq, heads):
+    q, k, v = [t.reshape(batch, seq, heads, 64).transpose(1, 2) for t in qkv.split(c, dim=1)]
+    return F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(batch * seq, c)
+
+
+@pytest.mark.parametrize("batch,seq,heads,amp", [(2, 4608, 2, 1.0), (1, 9216, 1, 1.0), (3, 4096, 1, 1.0), (1, 4096, 2, 3.0),
+                                                  (1, 5120, 1, 0.05),
+                                                  # not this kernel's shapes: passed through to the ordinary kernel
+                                                  (1, 4224, 1, 1.0), (2, 2304, 2, 1.0), (1, 200, 1, 1.0)])
+def test_attention_spatial_long(batch, seq, heads, amp):
+    """Frozen-reference kernel (csrc/attention_long.hip) vs fp32 attention: the long-row cases of the ordinary kernel with
+    their late dominant keys (those blocks overflow the frozen reference and take the second pass), peaky (amp 3: scores
+    of +-70) and flat (amp 0.05) rows; same tolerance.  The workspace starts with stale junk (the call zeroes it)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(seq + heads)
+    c = heads * 64
+    qkv = h(torch.randn(batch * seq, 3 * c, generator=g) * amp)
+    qkv[:, 2 * c:] = h(qkv[:, 2 * c:] / amp)
+    planted = []
+    if seq >= 4096:
+        planted = [(5, seq - 50, 3.0), (77, 130, 2.0), (300, seq // 2, 2.5), (40, 3000, 3.0), (100, 1000, 2.5)]
+        for qrow, krow, a in planted:
+            qkv[krow, c:c + 64] = h(qkv[qrow, :64] * a)            # head 0 of batch item 0
+    o, ws = _attn_long(ops, qkv.half().to(DEV), c, batch, seq, heads)
+    check(o, _sdpa(qkv, c, batch, seq, heads), l2=3e-3, mx=2e-2)
+    if seq >= 4096 and seq % 256 == 0:
+        flags = ws.cpu().view(batch * heads, seq // 256)
+        assert set(flags.unique().tolist()) <= {0, 1}
+        if amp == 1.0:        # unit-variance rows stay within 16 of their warm-up maximum; keys were planted in (0, 0) only
+            assert int(flags[1:].sum()) == 0
+
+
+@pytest.mark.parametrize("case", ["late_peaks_everywhere", "late_peak_one_block", "peak_in_own_tile", "peak_in_tile_zero",
+                                  "just_below_overflow", "just_above_overflow"])
+def test_attention_spatial_long_second_pass(case):
+    """Rows whose largest score arrives after the warm-up and exceeds the frozen reference by more than fp16 can hold are
+    flagged and recomputed by the ordinary kernel; peaks inside the warm-up (own tokens, tile 0) are not.  The result
+    must not depend on which kernel produced it, and the flags must be exactly the blocks that needed it."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(len(case))
+    batch, seq, heads = 2, 4096, 2
+    c = heads * 64
+    nblk = seq // 256
+    qkv = h(torch.randn(batch * seq, 3 * c, generator=g))
+    q, k = qkv[:, :c].view(batch, seq, heads, 64), qkv[:, c:2 * c].view(batch, seq, heads, 64)
+    expect = torch.zeros(batch, heads, nblk, dtype=torch.int32)
+    if case == "late_peaks_everywhere":      # every query has a key far away that matches it: 0.18 * 3 * |q|^2 ~ +35
+        for b in range(batch):
+            for hd in range(heads):
+                k[b, :, hd] = h(q[b, :, hd].roll(1500, dims=0) * 3.0)
+        expect[:] = 1
+    elif case == "late_peak_one_block":
+        k[1, 3000, 0] = h(q[1, 700, 0] * 2.5)          # query 700 of (item 1, head 0), block 2: +29 against a warm-up
+                                                       # maximum of ~5; the other queries see at most ~+13 from this key
+        expect[1, 0, 700 // 256] = 1
+    elif case == "peak_in_own_tile":
+        k[0, 1100, 1] = h(q[0, 1030, 1] * 2.5)         # key 1100: same block as query 1030 (1024..1279): the warm-up sees it
+    elif case == "peak_in_tile_zero":
+        k[1, 17, 1] = h(q[1, 2222, 1] * 2.5)
+    else:
+        # one query, one late key, score above the row's warm-up maximum by a chosen amount (log2 units): p = 2^gap
+        gap = 15.9 if case == "just_below_overflow" else 16.1
+        q[0, :, 0] *= 0.05                             # flat rows: warm-up maximum ~ 0
+        k[0, :, 0] *= 0.05
+        unit = torch.zeros(64); unit[0] = 8.0
+        q[0, 500, 0] = unit
+        k[0, 3500, 0] = 0.0
+        kk = k[0, :, 0].clone(); kk[3500] = 0.0
+        s_all = (q[0, 500, 0] @ kk.T) * 0.125 * 1.4426950408889634
+        warm = torch.cat([s_all[256:512], s_all[:64]]).max()      # own tiles of block 1 + tile 0
+        k[0, 3500, 0, 0] = h((warm + gap) / (8.0 * 0.125 * 1.4426950408889634))
+        expect[0, 0, 1] = 1 if gap > 16 else 0
+    qkv = h(qkv)
+    o, ws = _attn_long(ops, qkv.half().to(DEV), c, batch, seq, heads)
+    check(o, _sdpa(qkv, c, batch, seq, heads), l2=3e-3, mx=2e-2)
+    o2 = torch.empty_like(o)           # and against the ordinary kernel: same arithmetic, another reference point
+    d = qkv.half().to(DEV)
+    ops.attn_spatial(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o2, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=batch, seq=seq,
+                     heads=heads)
+    check(o, o2.float().cpu(), l2=2e-3, mx=1e-2)
+    flags = ws.cpu().view(batch, heads, nblk)
+    assert torch.equal(flags, expect), f"flagged blocks {flags.nonzero().tolist()} expected {expect.nonzero().tolist()}"
+
+
+def test_attention_spatial_long_argument_errors():
+    ops = _ops()
+    c = 64
+    d = torch.zeros(4096, 6 * c, dtype=torch.float16, device=DEV)
+    small = torch.zeros(16, dtype=torch.int32, device=DEV)
+    assert ops.attn_long_ws_bytes(14, 9216, 5) == 14 * 5 * 36 * 4
+    with pytest.raises(ops.HipKernelError, match="workspace"):
+        _attn_long(ops, d, 2 * c, 1, 4096, 2, ws=small)                   # two heads x 16 blocks need 32 words
+    with pytest.raises(ops.HipKernelError, match="stride"):
+        o = torch.empty(4096, c, dtype=torch.float16, device=DEV)
+        ops.attn_spatial_long(d, d, d, o, small, ldq=3 * c + 4, ldk=3 * c, ldv=3 * c, ldo=c, batch=1, seq=4096, heads=1)
+
+
 def _e4m3(t):
     """round-trip through OCP e4m3fn (what the fp8 path's quantiser stores), as fp32"""
     return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()

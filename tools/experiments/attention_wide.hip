@@ -33,7 +33,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <int QB>
+// V: experiment switches.  bit 0: no sched_group_barrier hints; bit 1 (TIMING ONLY): no rescale after the first tile;
+// bit 2 (TIMING ONLY): no row maximum after the first tile either.
+template <int QB, int V = 0>
 __global__ __launch_bounds__(256, 1) void attn_spatial_wide_kernel(
     const f16 *__restrict__ q, const f16 *__restrict__ k, const f16 *__restrict__ v, f16 *__restrict__ o,
     int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int seq, int heads, float scale_log2e) {
@@ -186,17 +188,37 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_wide_kernel(
     for (int qb = 0; qb < QB; ++qb) {
       f32x16(&sc)[2] = sacc[qb & 1];
       // ---- (a) row maximum of block qb   beside   PV of block qb-1
-      if (qb > 0) pv(qb - 1, pw[(qb - 1) & 1], vr);
-      float mt = fmaxf(fmaxf(sc[0][0], sc[0][1]), sc[0][2]);
+      // (V & 16: the maximum FIRST, the MFMAs behind it, so that the rescale decision is old news when the branch comes)
+      if (qb > 0 && !(V & 16)) pv(qb - 1, pw[(qb - 1) & 1], vr);
+      float mt = 0.f;
+      if (!(V & 4) || t == 0) {
+        if (V & 8) {
+          // tree: a wave alone on its SIMD pays the latency of every dependent max; four levels instead of sixteen
+          float a[11];
 #pragma unroll
-      for (int e = 3; e < 31; e += 2) mt = fmaxf(fmaxf(mt, sc[e >> 4][e & 15]), sc[(e + 1) >> 4][(e + 1) & 15]);
-      mt = fmaxf(mt, sc[1][15]);
-      {
+          for (int i = 0; i < 10; ++i) {
+            const int e = 3 * i;
+            a[i] = fmaxf(fmaxf(sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]), sc[(e + 2) >> 4][(e + 2) & 15]);
+          }
+          a[10] = fmaxf(sc[1][14], sc[1][15]);
+          const float b0 = fmaxf(fmaxf(a[0], a[1]), a[2]), b1 = fmaxf(fmaxf(a[3], a[4]), a[5]);
+          const float b2 = fmaxf(fmaxf(a[6], a[7]), a[8]), b3 = fmaxf(a[9], a[10]);
+          mt = fmaxf(fmaxf(fmaxf(b0, b1), b2), b3);
+        } else {
+          mt = fmaxf(fmaxf(sc[0][0], sc[0][1]), sc[0][2]);
+#pragma unroll
+          for (int e = 3; e < 31; e += 2) mt = fmaxf(fmaxf(mt, sc[e >> 4][e & 15]), sc[(e + 1) >> 4][(e + 1) & 15]);
+          mt = fmaxf(mt, sc[1][15]);
+        }
         float ma = mt, mb = mt;
         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
         mt = fmaxf(ma, mb);
       }
-      if (qb > 0) {                                   // 12 MFMAs beside ~24 vector instructions
+      if (qb > 0 && (V & 16)) {
+        __builtin_amdgcn_sched_barrier(0);
+        pv(qb - 1, pw[(qb - 1) & 1], vr);
+      }
+      if (qb > 0 && !(V & 1) && !(V & 16)) {          // 12 MFMAs beside ~24 vector instructions
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
@@ -205,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_wide_kernel(
       }
       constexpr float RESCALE_LOG2 = 8.0f;
       const float delta = t == 0 ? mt : (mt > RESCALE_LOG2 ? mt : 0.f);
-      if (__builtin_amdgcn_ballot_w64(delta != 0.f) != 0) {       // rare after the first tile
+      if (((V & 6) == 0 || t == 0) && __builtin_amdgcn_ballot_w64(delta != 0.f) != 0) {       // rare after the first tile
         const float alpha = t == 0 ? 1.f : fast_exp2(-delta);
         lacc[qb][0] *= alpha;
 #pragma unroll
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void attn_spatial_wide_kernel(
           const f32x2 p = {fast_exp2(sc[kt][e]), fast_exp2(sc[kt][e + 1])};
           pc[kt][e >> 3][(e & 7) >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, f16x2));
         }
-      if (qb + 1 < QB) {                              // 8 MFMAs (+ their 8 K reads) beside 48 vector instructions
+      if (qb + 1 < QB && !(V & 1)) {                  // 8 MFMAs (+ their 8 K reads) beside 48 vector instructions
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // the eight K fragments first
         __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);       // a first run of exponentials covers their latency
 #pragma unroll
@@ -280,5 +302,27 @@ int sp_attn_wide_launch(const void *q, const void *k, const void *v, void *o, in
     hipLaunchKernelGGL(attn_spatial_wide_kernel<2>, dim3(seq / 256, batch * heads), dim3(256), 0, stream, (const f16 *)q,
                        (const f16 *)k, (const f16 *)v, (f16 *)o, ldq, ldk, ldv, ldo, seq, heads, scale_log2e);
   SP_CHECK_LAUNCH("sp_attn_spatial_f16(wide)");
+  return SP_OK;
+}
+
+// experiments harness (linked into libsvdpipe_hip_exp.so by hand: see tools/bench_attn_wide.py)
+extern "C" int sp_exp_attn_wide(const void *q, const void *k, const void *v, void *o, int64_t ldq, int64_t ldk, int64_t ldv,
+                                int64_t ldo, int batch, int seq, int heads, float scale, int qb, int variant, void *stream) {
+  const float sl = scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  if (seq % (128 * qb)) return -1;
+  SP_CLEAR_STALE_ERROR();
+#define WIDE(QBV, VV)                                                                                                     \
+  hipLaunchKernelGGL((attn_spatial_wide_kernel<QBV, VV>), dim3(seq / (128 * QBV), batch * heads), dim3(256), 0, st,        \
+                     (const f16 *)q, (const f16 *)k, (const f16 *)v, (f16 *)o, ldq, ldk, ldv, ldo, seq, heads, sl)
+  if (qb == 3) { switch (variant) { case 1: WIDE(3, 1); break; case 7: WIDE(3, 7); break; case 9: WIDE(3, 9); break;
+                                    case 11: WIDE(3, 11); break; case 8: WIDE(3, 8); break; case 24: WIDE(3, 24); break; case 25: WIDE(3, 25); break; case 10: WIDE(3, 10); break; case 6: WIDE(3, 6); break; default: return -2; } }
+  else if (qb == 4) { switch (variant) { case 1: WIDE(4, 1); break; case 9: WIDE(4, 9); break; case 8: WIDE(4, 8); break;
+                                         case 11: WIDE(4, 11); break; default: return -2; } }
+  else if (qb == 2) { switch (variant) { case 1: WIDE(2, 1); break; case 7: WIDE(2, 7); break; case 9: WIDE(2, 9); break;
+                                         case 11: WIDE(2, 11); break; case 8: WIDE(2, 8); break; case 6: WIDE(2, 6); break; case 0: WIDE(2, 0); break; case 10: WIDE(2, 10); break; case 16: WIDE(2, 16); break; case 24: WIDE(2, 24); break; case 25: WIDE(2, 25); break; case 17: WIDE(2, 17); break; default: return -2; } }
+  else return -3;
+#undef WIDE
+  SP_CHECK_LAUNCH("sp_exp_attn_wide");
   return SP_OK;
 }

@@ -64,6 +64,36 @@ def attn_spatial(rng, g, fp8):
     return e
 
 
+def attn_long(rng, g):
+    """Frozen-reference kernel: row lengths on both sides of its contract, amplitudes from flat to peaky, and (half of
+    the cases) late keys that match a query far above its warm-up maximum, so that blocks take the second pass."""
+    batch, heads = rng.choice([1, 2]), rng.choice([1, 2, 5])
+    seq = rng.choice([4096, 4352, 4608, 5120, 4224, 4097, 2304])
+    c = heads * 64
+    amp = rng.choice([0.25, 1.0, 1.0, 2.0, 3.0])
+    qkv = h(torch.randn(batch * seq, 3 * c, generator=g) * amp)
+    qkv[:, 2 * c:] = h(qkv[:, 2 * c:] / amp)
+    planted = rng.random() < 0.5
+    if planted:
+        x = qkv.view(batch, seq, 3 * heads, 64)
+        for _ in range(rng.choice([1, 3, 20])):
+            b, hd, qi, ki = rng.randrange(batch), rng.randrange(heads), rng.randrange(seq), rng.randrange(seq)
+            x[b, ki, heads + hd] = h(x[b, qi, hd] * rng.choice([2.0, 3.0]) / max(amp * amp, 0.25))
+    d = qkv.half().to(DEV)
+    buf, o = guarded(batch * seq, c)
+    ws = torch.full((ops.attn_long_ws_bytes(batch, seq, heads) // 4 + 1,), -1, dtype=torch.int32, device=DEV)
+    ops.attn_spatial_long(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o, ws, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=batch,
+                          seq=seq, heads=heads)
+    torch.cuda.synchronize()
+    q, k, v = [t.reshape(batch, seq, heads, 64).transpose(1, 2) for t in qkv.split(c, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(batch * seq, c)
+    what = f"attn_spatial_long batch={batch} seq={seq} heads={heads} amp={amp} planted={planted}"
+    e = rel_l2(check_guard(buf, batch * seq, what), ref)
+    assert e <= 3e-3, f"rel_l2={e:.3e}: {what}"
+    assert int(ws[-1]) == -1, "flag words written past the workspace: " + what
+    return e
+
+
 def attn_temporal(rng, g):
     batch, heads, frames, hw = rng.choice([1, 2]), rng.choice([1, 3, 5]), rng.choice([1, 2, 14, 16, 17, 25, 32]), rng.choice([1, 3, 50, 257])
     c = heads * 64
@@ -225,7 +255,8 @@ def gelu(rng, g):
 
 
 def one(rng, g):
-    kind = rng.choice(["as", "as", "as8", "at", "gn", "gn", "ln", "lns", "lns", "gv", "asm", "asm", "sm", "gl"])
+    kind = rng.choice(["as", "as", "as8", "at", "gn", "gn", "ln", "lns", "lns", "gv", "asm", "asm", "sm", "gl", "al"])
+    if kind == "al": return attn_long(rng, g)
     if kind == "asm": return attn_small(rng, g)
     if kind == "sm": return softmax_rows(rng, g)
     if kind == "gl": return gelu(rng, g)

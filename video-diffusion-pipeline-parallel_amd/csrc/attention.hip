@@ -44,10 +44,13 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(
     const f16 *__restrict__ q, const f16 *__restrict__ k, const f16 *__restrict__ v, f16 *__restrict__ o,
     int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int seq, int heads, float scale_log2e,
-    const char *__restrict__ zero) {
+    const char *__restrict__ zero, const unsigned *__restrict__ only_flagged) {
   constexpr int KV = 64;
   constexpr int K_BYTES = KV * 128, STAGE = 2 * K_BYTES, RING = 2;
   __shared__ __attribute__((aligned(16))) char smem[RING * STAGE];
+  // second pass of sp_attn_spatial_long_f16 (attention_long.hip): one word per 256 query rows of a (batch item, head),
+  // non-zero = do these rows (uniform: a scalar load and branch)
+  if (only_flagged && only_flagged[(int64_t)blockIdx.y * ((seq + 255) >> 8) + (blockIdx.x >> 1)] == 0) return;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -400,19 +403,26 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(
 
 }  // namespace
 
-extern "C" int sp_attn_spatial_f16(const void *q, const void *k, const void *v, void *o, int64_t ldq,
-                                   int64_t ldk, int64_t ldv, int64_t ldo, int batch, int seq, int heads,
-                                   float scale, const void *zero_page, void *stream) {
-  SP_REQUIRE(q && k && v && o && zero_page, "sp_attn_spatial_f16: null pointer");
-  SP_REQUIRE(batch > 0 && seq > 0 && heads > 0, "sp_attn_spatial_f16: batch/seq/heads must be positive");
-  SP_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "sp_attn_spatial_f16: strides must be multiples of 8");
-  SP_REQUIRE((int64_t)batch * heads <= 65535, "sp_attn_spatial_f16: batch*heads too large");
+int sp_attn_spatial_launch(const void *q, const void *k, const void *v, void *o, int64_t ldq, int64_t ldk, int64_t ldv,
+                           int64_t ldo, int batch, int seq, int heads, float scale, const void *zero_page,
+                           const unsigned *only_flagged, void *stream, const char *who) {
+  SP_REQUIRE(q && k && v && o && zero_page, "%s: null pointer", who);
+  SP_REQUIRE(batch > 0 && seq > 0 && heads > 0, "%s: batch/seq/heads must be positive", who);
+  SP_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "%s: strides must be multiples of 8", who);
+  SP_REQUIRE((int64_t)batch * heads <= 65535, "%s: batch*heads too large", who);
   SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(attn_spatial_kernel, dim3((seq + 127) / 128, batch * heads), dim3(256), 0,
                      (hipStream_t)stream, (const f16 *)q, (const f16 *)k, (const f16 *)v, (f16 *)o, ldq, ldk,
-                     ldv, ldo, seq, heads, scale * 1.4426950408889634f, (const char *)zero_page);
-  SP_CHECK_LAUNCH("sp_attn_spatial_f16");
+                     ldv, ldo, seq, heads, scale * 1.4426950408889634f, (const char *)zero_page, only_flagged);
+  SP_CHECK_LAUNCH(who);
   return SP_OK;
+}
+
+extern "C" int sp_attn_spatial_f16(const void *q, const void *k, const void *v, void *o, int64_t ldq,
+                                   int64_t ldk, int64_t ldv, int64_t ldo, int batch, int seq, int heads,
+                                   float scale, const void *zero_page, void *stream) {
+  return sp_attn_spatial_launch(q, k, v, o, ldq, ldk, ldv, ldo, batch, seq, heads, scale, zero_page, nullptr, stream,
+                                "sp_attn_spatial_f16");
 }
 
 extern "C" int sp_attn_temporal_f16(const void *q, const void *k, const void *v, void *o, int64_t ldq,

@@ -1,0 +1,507 @@
+// Spatial self-attention for LONG rows (head_dim 64, fp16 in / fp32 accumulate, no mask): one wave per SIMD, two query
+// blocks (64 rows) per wave, a softmax reference that is frozen after a warm-up, and a steady-state tile whose issue
+// order is written out by hand.
+//
+// Why a second kernel.  attention.hip's kernel (three waves per SIMD, 32 query rows each) is bound by vector ISSUE; a
+// third of what a wave issues per K/V tile does not scale with its query rows (LDS-DMA pieces, K / V fragment reads,
+// barrier, loop), and the online-softmax bookkeeping -- 21 instructions for the row maximum and a data-dependent
+// branch for the rescale -- sits in the middle of every tile.  Two query blocks per wave halve the first group per
+// row; the second leaves the loop as follows.
+//
+// Frozen reference.  Every workgroup first runs WARM tiles with the ordinary online softmax (row maximum, rescale): the
+// four K/V tiles that hold its own 256 tokens -- in self-attention over an image a query's largest scores sit on itself
+// and its neighbours -- and tile 0.  Then the reference m of each row is FROZEN at the exact maximum seen so far and
+// the remaining tiles run without maximum and without rescale: p = 2^(s - m), fp32, rounded to fp16.  That is exact
+// arithmetic with a fixed reference as long as no p overflows fp16, i.e. as long as no later score exceeds the
+// warm-up maximum by 16 (log2 units; 11 nats).  The kernel does not assume it: an overflowing p becomes +inf, reaches
+// the row sum l through the matrix pipe (as inf, or NaN from 0 x inf), and a wave that ends with a non-finite l raises
+// its workgroup's word in `flags`.  The host entry then launches attention.hip's kernel over the flagged 256-row
+// blocks only (a workgroup whose word is zero exits at once), which overwrites their rows.  So results never depend on
+// the speculation, only the time does: nothing flagged costs one near-empty launch; everything flagged costs this
+// kernel plus the ordinary one (tools/bench_attn_long.py modes l / h; tools/long_attn_flags.py counts the flagged
+// blocks inside the UNet: none at the benchmark's shapes and weights).  l >= 1 needs no check: the reference is a
+// score of the row.  A proven bound instead of the speculation was tried first (Cauchy-Schwarz, |q| max|k| from a
+// pre-pass, reference max(tile-0 maximum, bound - 15)): it never overflows but is so loose -- twice the true maximum
+// for Gaussian data -- that with q, k of 1.5x unit variance every row lost its mass below fp16's range.
+//
+// Written-out schedule (steady2 below).  A wave alone on its SIMD stands still whenever its next instruction waits, so
+// the order matters and hipcc's schedulers did not deliver it: the same source gave 1.46-1.80 ms at 14 x 9,216 x 5
+// depending on incidental changes, and sched_group_barrier pipelines were followed only in part (the VALU mask 0x002
+// does not contain the transcendentals, 0x400).  The tile is therefore a fixed sequence of steps -- one MFMA plus its
+// share of the other block's exponentials, one LDS read or LDS-DMA piece here and there -- separated by
+// sched_barrier(0); the converts are pinned to their step through an empty volatile asm on their result (otherwise an
+// IR pass merges the four converts of an operand and the exponentials follow them).  Measured:
+// ~2,000 shader cycles per tile at any load -- 1,150 of them MFMA; the rest is the wave's own issue time, v_exp_f32 at
+// ~11 cycles and v_cvt_pk at ~6 (tools/issue_probe.hip), which a single in-order wave overlaps only in part.
+//
+// Structure: workgroup = 4 waves x 2 x 32 query rows, 3-deep K/V ring by LDS-DMA; transposed scores, accumulators start
+// from -m, exp2 on pre-scaled Q, row sums on the matrix pipe, P as accumulator-as-operand (see attention.hip).  Built
+// with -mllvm -amdgpu-mfma-vgpr-form=1 (Makefile).  ONE __shared__ object only: with two, hipcc's LDS lowering tags
+// every access with alias scopes, the waitcnt pass then knows that the K reads may alias the LDS-DMA in flight and puts
+// s_waitcnt vmcnt(0) at the top of every tile (measured: 2.15 ms instead of 1.5 ms).
+// Host contract: seq a multiple of 256 and >= 4096; everything else goes to attention.hip's kernel.
+#include "common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int QB>
+__global__ __launch_bounds__(256, 1) void attn_long_kernel(
+    const f16 *__restrict__ q, const f16 *__restrict__ k, const f16 *__restrict__ v, f16 *__restrict__ o,
+    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int seq, int heads, float scale_log2e,
+    unsigned *__restrict__ flags) {
+  constexpr int KV = 64;
+  constexpr int K_BYTES = KV * 128, STAGE = 2 * K_BYTES, RING = 3;
+  constexpr int OWN = 2 * QB;                // K/V tiles that hold this workgroup's own tokens
+  constexpr int WARM = OWN + 1;              // + tile 0
+  __shared__ __attribute__((aligned(16))) char smem[RING * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.y;
+  const int b = bh / heads, hd = bh - b * heads;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)b * seq;
+  const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
+
+  // Q fragments (B operand of S^T = K.Q^T), pre-multiplied by scale*log2(e) (fp32 product, one rounding to fp16)
+  f16x8 qf[QB][4];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const f16 *qp = q + (row0 + q0 + qb * 32 + r) * ldq + hd * 64 + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const f16x8 raw = *(const f16x8 *)(qp + 16 * s);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[qb][s][e] = (f16)((float)raw[e] * scale_log2e);
+    }
+  }
+
+  // K/V staging as in attention.hip: each wave moves 16 rows of K and of V per tile (2 x 2 LDS-DMA pieces of 8 rows)
+  const int lrow = lane >> 3, lchunk = lane & 7;
+  unsigned kofl[2], vofl[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wave * 16 + i * 8 + lrow;
+    kofl[i] = (unsigned)((row * ldk + ((lchunk ^ ((row >> 1) & 7)) << 3)) * 2);
+    vofl[i] = (unsigned)((row * ldv + ((lchunk ^ (((row >> 1) & 1) << 2)) << 3)) * 2);
+  }
+  const int64_t kstep = (int64_t)KV * ldk * 2, vstep = (int64_t)KV * ldv * 2;
+
+  // operand read offsets (see attention.hip)
+  int koff[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) koff[kt] = (kt * 32 + r) * 128;
+  int kswz = (r >> 1) & 7, hq = h;            // (not const: see the live-range cut in front of the steady-state loop)
+  const int g = lane >> 4, i16 = lane & 15, q_ = i16 >> 2, pp = i16 & 3;
+  const int vrow_l = 4 * (g >> 1) + q_;
+  const int vchunk_l = 2 * (g & 1) + (pp >> 1);
+  const int vswz = (q_ >> 1) << 2;
+  const int vbyte_l = (pp & 1) * 8;
+  int vlane0 = vrow_l * 128 + ((vchunk_l ^ vswz) << 4) + vbyte_l;
+  int vlane1 = vrow_l * 128 + (((4 + vchunk_l) ^ vswz) << 4) + vbyte_l;
+
+  // selector operand of the row-sum MFMA (attention.hip): element 0 of the 16x16 accumulator = this lane's own row sum
+  f16x8 lsel;
+  {
+    const int m16 = lane & 15, kb4 = lane >> 4;
+    const bool one = ((m16 & 7) == 0 && (kb4 & 1) == 0) || ((m16 & 7) == 4 && (kb4 & 1) == 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lsel[e] = one ? (f16)1.f : (f16)0.f;
+  }
+
+  f32x16 oacc[QB][2], negm[QB];
+  f32x4 lacc[QB];
+  float m_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = 0.f;
+    lacc[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { oacc[qb][0][e] = 0.f; oacc[qb][1][e] = 0.f; negm[qb][e] = 0.f; }
+  }
+  const int ntiles = seq / KV;
+
+  // Visit order of the K/V tiles: the OWN tiles of this workgroup's tokens first, then 0 .. ntiles-1 without them (so
+  // tile 0 closes the warm-up, and from there on the workgroups of a (batch item, head) walk K/V in the same order, a
+  // few tiles apart: what one of them brings into its XCD's L2 the next ones find there).
+  const int own0 = blockIdx.x * OWN;
+  const char *kbase = (const char *)(k + row0 * ldk + hd * 64);
+  const char *vbase = (const char *)(v + row0 * ldv + hd * 64);
+  auto stage = [&](int i, int buf) {
+    const int tl = i < OWN ? own0 + i : (i - OWN < own0 ? i - OWN : i);
+    const char *kb = kbase + tl * kstep, *vb = vbase + tl * vstep;
+    char *sk = smem + buf * STAGE;
+    char *sv = sk + K_BYTES;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      glds16(kb + kofl[j], sk + (wave * 16 + j * 8) * 128);
+      glds16(vb + vofl[j], sv + (wave * 16 + j * 8) * 128);
+    }
+  };
+  // 3-deep K/V ring: tiles i+1 and i+2 are in flight while tile i is consumed (ntiles >= 64: host contract)
+  stage(0, 0);
+  stage(1, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // S^T = K.Q^T - m for block qb (8 MFMAs; the eight K fragments are requested ahead of the first MFMA: a wave alone
+  // on its SIMD has nobody to cover an LDS round trip in front of each one)
+  auto qk = [&](int qb, const char *sk, f32x16 (&sacc)[2]) {
+    f16x8 kf[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[kt][s] = *(const f16x8 *)(sk + koff[kt] + (((2 * s + hq) ^ kswz) << 4));
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s], qf[qb][s], s == 0 ? negm[qb] : sacc[kt], 0, 0, 0);
+  };
+  // O^T += V^T.P^T and the row sums for block qb (8 + 4 MFMAs, V fragments in registers)
+  auto pv = [&](int qb, const u32x4 (&pw)[2][2], const u32x2 (&vr)[2][8]) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const u32x4 vw = {vr[dt][4 * kt + 2 * s][0], vr[dt][4 * kt + 2 * s][1], vr[dt][4 * kt + 2 * s + 1][0],
+                            vr[dt][4 * kt + 2 * s + 1][1]};
+          oacc[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vw),
+                                                               __builtin_bit_cast(f16x8, pw[kt][s]), oacc[qb][dt], 0, 0, 0);
+          if (dt == 0)
+            lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lsel, __builtin_bit_cast(f16x8, pw[kt][s]), lacc[qb], 0, 0, 0);
+        }
+  };
+
+  // One warm-up tile (visit i, ring slot buf): online softmax with the exact running maximum as the reference; hipcc
+  // schedules it (five tiles of 144).
+  auto warm_tile = [&](int i, int buf) {
+    if (i + 2 < ntiles) stage(i + 2, buf >= 1 ? buf - 1 : RING - 1);       // slot of visit i-1 = (i+2) % 3
+    const char *sk = smem + buf * STAGE;
+    const char *sv = sk + K_BYTES;
+
+    f32x16 sacc[2][2];                       // scores of the block in its softmax / of the next block
+    u32x4 pw[2][2][2];                       // packed probabilities of the block in its softmax / of the previous block
+    qk(0, sk, sacc[0]);
+    // V fragments of the whole tile, read once for all QB blocks (inline asm: for the builtin hipcc waits for the
+    // LDS-DMA in flight); issued behind the first score MFMAs, which cover the read latency
+    u32x2 vr[2][8];
+    {
+      const unsigned va[2] = {(unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)(sv + vlane0),
+                              (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)(sv + vlane1)};
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[dt][j]) : "v"(va[dt]), "n"(j * 8 * 128) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(vr[0][0]), "+v"(vr[0][1]), "+v"(vr[0][2]), "+v"(vr[0][3]), "+v"(vr[0][4]), "+v"(vr[0][5]),
+                     "+v"(vr[0][6]), "+v"(vr[0][7]), "+v"(vr[1][0]), "+v"(vr[1][1]), "+v"(vr[1][2]), "+v"(vr[1][3]),
+                     "+v"(vr[1][4]), "+v"(vr[1][5]), "+v"(vr[1][6]), "+v"(vr[1][7])::"memory");
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      f32x16(&sc)[2] = sacc[qb & 1];
+      // ---- (a) PV of block qb-1 [matrix]   beside   the row maximum of block qb [vector]
+      if (qb > 0) pv(qb - 1, pw[(qb - 1) & 1], vr);
+      {
+        float mt = fmaxf(fmaxf(sc[0][0], sc[0][1]), sc[0][2]);
+#pragma unroll
+        for (int e = 3; e < 31; e += 2) mt = fmaxf(fmaxf(mt, sc[e >> 4][e & 15]), sc[(e + 1) >> 4][(e + 1) & 15]);
+        mt = fmaxf(mt, sc[1][15]);
+        float ma = mt, mb = mt;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+        mt = fmaxf(ma, mb);
+        // scores are relative to the running maximum: mt > 0 raises it (visit 0: sets it; the accumulators are zero)
+        const float delta = i == 0 ? mt : fmaxf(mt, 0.f);
+        if (__builtin_amdgcn_ballot_w64(delta != 0.f) != 0) {
+          const float alpha = i == 0 ? 1.f : fast_exp2(-delta);
+          lacc[qb][0] *= alpha;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { oacc[qb][0][e] *= alpha; oacc[qb][1][e] *= alpha; }
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[kt][e] -= delta;
+          m_run[qb] += delta;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) negm[qb][e] = -m_run[qb];
+        }
+      }
+      // ---- (b) exponentials of block qb [vector]   beside   the scores of block qb+1 [matrix]
+      if (qb + 1 < QB) qk(qb + 1, sk, sacc[(qb + 1) & 1]);
+      u32x4(&pc)[2][2] = pw[qb & 1];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const f32x2 p = {fast_exp2(sc[kt][e]), fast_exp2(sc[kt][e + 1])};
+          pc[kt][e >> 3][(e & 7) >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, f16x2));
+        }
+    }
+    pv(QB - 1, pw[(QB - 1) & 1], vr);
+    // visit i+1 landed (this wave's pieces; visit i+2's four may stay in flight); every wave is done reading this one
+    if (i + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // Steady state, two query blocks: the issue order is written out, one MFMA and its share of the other block's
+  // exponentials per step, with a scheduling barrier after every step (tools/issue_probe.hip: a wave overlaps its own
+  // MFMAs with its vector instructions almost perfectly when they alternate at this grain -- 8 x (MFMA, 2 exp, 1 cvt)
+  // takes 149 ns against 139 ns for the 8 MFMAs alone -- and hipcc's group scheduler does not reliably produce that
+  // from hints).  A "quarter" is 2 exponentials + 1 packed convert (~23 cycles), an MFMA 32 (row sums: 16).
+  //   row 1   S0[keys 0-31] x4                         |  -
+  //   rows 2-4  S0[32-63], S1[0-31], S1[32-63] x4 each  |  P0 quarters: (0-31, first 8), (0-31, last 8), (32-63, first 8)
+  //   row 5   PV0(0-31): 6 MFMAs                        |  P0 (32-63, last 8)
+  //   rows 6-9  PV0(32-63) 2x3, PV1(0-31) 2x3           |  P1, 8 scores per row
+  //   row 10  PV1(32-63): 6 MFMAs                       |  -
+#ifdef LONG_TRACE
+  // shader cycles (s_memtime) up to each mark, summed over the steady tiles.  The stamp is a scalar memory read: its
+  // s_waitcnt lgkmcnt(0) also drains the LDS reads in flight, so their latency shows in the segment that issued them.
+  unsigned tr[16] = {0}, tprev = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+  f16x8 kf[2][4];                            // K fragments of the tile: read under row 10 of the tile before
+  auto read_k = [&](int buf) {
+    const char *sk = smem + buf * STAGE;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[kt][s] = *(const f16x8 *)(sk + koff[kt] + (((2 * s + hq) ^ kswz) << 4));
+  };
+  auto steady2 = [&](int i, int buf) {
+    static_assert(QB == 2, "the written-out schedule is for two query blocks");
+    // The four LDS-DMA pieces of visit i+2 are issued one at a time between the rows: back to back at the top of the
+    // tile (all four waves at once, right after the barrier) they queue up behind each other in the texture path and
+    // the issuing wave -- alone on its SIMD -- stands still for ~540 cycles per tile (tools/trace_attn_long.py).
+    // Past the end the last tile is fetched again into the free slot: no branch in the tile, one uniform vmcnt.
+    const int vis = i + 2 < ntiles ? i + 2 : ntiles - 1;
+    const int tl2 = vis < OWN ? own0 + vis : (vis - OWN < own0 ? vis - OWN : vis);
+    const char *kb2 = kbase + tl2 * kstep, *vb2 = vbase + tl2 * vstep;
+    char *sk2 = smem + (buf >= 1 ? buf - 1 : RING - 1) * STAGE;   // slot of visit i-1 = (i+2) % 3
+    auto dma = [&](int j, bool v_piece) {
+      if (v_piece) glds16(vb2 + vofl[j], sk2 + K_BYTES + (wave * 16 + j * 8) * 128);
+      else glds16(kb2 + kofl[j], sk2 + (wave * 16 + j * 8) * 128);
+    };
+    const char *sk = smem + buf * STAGE;
+    const char *sv = sk + K_BYTES;
+    f32x16 sc[2][2];                         // [block][key half]
+    unsigned pw[2][2][2][4];                 // [block][key half][8 scores][pair]: scalars, so that no pass merges the converts
+    u32x2 vr[2][8];
+    auto S = [&](int b, int kt, int s) {
+      sc[b][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s], qf[b][s], s == 0 ? negm[b] : sc[b][kt], 0, 0, 0);
+    };
+    auto Q = [&](int b, int kt, int s, int q) {                 // scores 8s + 2q, 8s + 2q + 1 of (block, key half)
+      const int e = 8 * s + 2 * q;
+      const f32x2 p = {fast_exp2(sc[b][kt][e]), fast_exp2(sc[b][kt][e + 1])};
+      pw[b][kt][s][q] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, f16x2));
+      asm volatile("" : "+v"(pw[b][kt][s][q]));                 // computed HERE (ordered against the scheduling barriers)
+    };
+    auto P = [&](int b, int kt, int s, int which) {             // which: 0 = O (channels 0-31), 1 = row sums, 2 = O (32-63)
+      const u32x4 pk = {pw[b][kt][s][0], pw[b][kt][s][1], pw[b][kt][s][2], pw[b][kt][s][3]};
+      if (which == 1) {
+        lacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lsel, __builtin_bit_cast(f16x8, pk), lacc[b], 0, 0, 0);
+      } else {
+        const int dt = which >> 1;
+        const u32x4 vw = {vr[dt][4 * kt + 2 * s][0], vr[dt][4 * kt + 2 * s][1], vr[dt][4 * kt + 2 * s + 1][0],
+                          vr[dt][4 * kt + 2 * s + 1][1]};
+        oacc[b][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vw), __builtin_bit_cast(f16x8, pk),
+                                                            oacc[b][dt], 0, 0, 0);
+      }
+    };
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef LONG_TRACE_ROWS
+#define STAMP(k) { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); tr[k] += t_ - tprev; tprev = t_; SB(); }
+    STAMP(0);
+#else
+#define STAMP(k)
+#endif
+    // LDS reads one or two per step as well (four waves reading a tile's 8 KB of K or V at the same moment wait on each
+    // other for ~250 cycles): V fragments of keys 0-31 under row 4, of keys 32-63 under row 5 (they take the registers
+    // the K fragments leave), the next tile's K fragments under rows 8-10
+    const unsigned va[2] = {(unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)(sv + vlane0),
+                            (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)(sv + vlane1)};
+    auto RV = [&](int j) {                                       // (inline asm: for the builtin hipcc waits for the LDS-DMA in flight)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[dt][j]) : "v"(va[dt]), "n"(j * 8 * 128) : "memory");
+    };
+    const char *skn = smem + (buf + 1 == RING ? 0 : buf + 1) * STAGE;
+    auto RK = [&](int n) { kf[n >> 2][n & 3] = *(const f16x8 *)(skn + koff[n >> 2] + (((2 * (n & 3) + hq) ^ kswz) << 4)); };
+    // row 1
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { S(0, 0, s); SB(); }
+    dma(0, false); SB();
+    STAMP(1);
+    // rows 2-3
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { S(0, 1, s); Q(0, 0, 0, s); SB(); }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { S(1, 0, s); Q(0, 0, 1, s); SB(); }
+    dma(0, true); SB();
+    STAMP(2);
+    // row 4
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { S(1, 1, s); Q(0, 1, 0, s); RV(s); SB(); }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vr[0][0]), "+v"(vr[0][1]), "+v"(vr[0][2]), "+v"(vr[0][3]), "+v"(vr[1][0]), "+v"(vr[1][1]), "+v"(vr[1][2]),
+                   "+v"(vr[1][3])::"memory");
+    SB();
+    STAMP(3);
+    // row 5
+    P(0, 0, 0, 0); Q(0, 1, 1, 0); RV(4); SB();
+    P(0, 0, 0, 1); Q(0, 1, 1, 1); RV(5); SB();
+    P(0, 0, 0, 2); Q(0, 1, 1, 2); RV(6); SB();
+    P(0, 0, 1, 0); Q(0, 1, 1, 3); RV(7); SB();
+    P(0, 0, 1, 1); SB();
+    P(0, 0, 1, 2); SB();
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vr[0][4]), "+v"(vr[0][5]), "+v"(vr[0][6]), "+v"(vr[0][7]), "+v"(vr[1][4]), "+v"(vr[1][5]), "+v"(vr[1][6]),
+                   "+v"(vr[1][7])::"memory");
+    SB();
+    STAMP(4);
+    // Every wave has read what it needs of this tile, and visit i+1 has landed: its four pieces are the oldest of the
+    // six in flight (visit i+2's first two were issued above).
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    SB();
+    STAMP(5);
+    // rows 6-9: three MFMAs of one block beside the four quarters of the other's next eight scores
+#define ROW(pb, pkt, ps, qkt, qs, X0, X1, X2)                              \
+    P(pb, pkt, ps, 0); Q(1, qkt, qs, 0); Q(1, qkt, qs, 1); X0; SB();       \
+    P(pb, pkt, ps, 1); Q(1, qkt, qs, 2); X1; SB();                         \
+    P(pb, pkt, ps, 2); Q(1, qkt, qs, 3); X2; SB();
+    ROW(0, 1, 0, 0, 0, dma(1, false), , )
+    ROW(0, 1, 1, 0, 1, dma(1, true), , )
+    STAMP(6);
+    ROW(1, 0, 0, 1, 0, RK(0), RK(1), RK(2))
+    ROW(1, 0, 1, 1, 1, RK(3), RK(4), RK(5))
+#undef ROW
+    STAMP(7);
+    // row 10
+    P(1, 1, 0, 0); RK(6); SB();
+    P(1, 1, 0, 1); RK(7); SB();
+    P(1, 1, 0, 2); SB();
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { P(1, 1, 1, w); SB(); }
+    STAMP(8);
+#undef SB
+#undef STAMP
+  };
+
+  int buf = 0;
+  for (int i = 0; i < WARM; ++i) {
+    warm_tile(i, buf);
+    buf = buf + 1 == RING ? 0 : buf + 1;
+  }
+  // The loop-invariant operands (Q fragments, LDS / DMA lane offsets) get fresh live ranges here: the warm-up loop needs
+  // ~280 registers and parks some of them in AGPRs, and without the cut they would stay there for the steady-state loop
+  // too (19 v_accvgpr_read per tile in front of the first MFMA); on its own that loop fits the 256 VGPRs.
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[qb][s]));
+  asm volatile("" : "+v"(koff[0]), "+v"(koff[1]), "+v"(vlane0), "+v"(vlane1), "+v"(kofl[0]), "+v"(kofl[1]), "+v"(vofl[0]),
+               "+v"(vofl[1]), "+v"(lsel), "+v"(kswz), "+v"(hq));
+  read_k(buf);
+#ifdef LONG_TRACE
+  const unsigned long long tc0 = __builtin_amdgcn_s_memtime(), tw0 = wall_clock64();
+#endif
+  for (int i = WARM; i < ntiles; ++i) {
+    steady2(i, buf);
+    buf = buf + 1 == RING ? 0 : buf + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched last tile (steady2) is still on its way into LDS
+
+#ifdef LONG_TRACE
+  tr[14] = (unsigned)(__builtin_amdgcn_s_memtime() - tc0);             // steady loop: shader cycles / 100 MHz ticks
+  tr[15] = (unsigned)(wall_clock64() - tw0);
+  if (blockIdx.x == 3 && blockIdx.y == LONG_TRACE && tid < 16) flags[gridDim.x * gridDim.y + tid] = tr[tid];
+#endif
+  // a probability that overflowed fp16 reached the row sum as inf (or NaN): this workgroup's rows are done again by
+  // attention.hip's kernel (host entry below); what is stored here for them is overwritten
+  {
+    bool bad = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) bad = bad || !(lacc[qb][0] < 3.0e38f);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) flags[(int64_t)bh * gridDim.x + blockIdx.x] = 1u;
+  }
+
+  // ---- finalize: O^T[d][q] / l ; lane holds d = 32dt + (e&3) + 8(e>>2) + 4h for query q0 + 32 qb + r
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float inv = 1.0f / lacc[qb][0];
+    f16 *op = o + (row0 + q0 + qb * 32 + r) * ldo + hd * 64 + 4 * h;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (f16)(oacc[qb][dt][4 * c + e] * inv);
+        *(f16x4 *)(op + 32 * dt + 8 * c) = w;
+      }
+  }
+}
+
+}  // namespace
+
+constexpr int LONG_QB = 2;
+constexpr int LONG_ROWS = 128 * LONG_QB;       // query rows per workgroup = rows per flag word
+
+// attention.hip: sp_attn_spatial_f16's launcher; with `only_flagged`, 128-row workgroups whose 256-row block has a zero
+// word exit at once
+int sp_attn_spatial_launch(const void *q, const void *k, const void *v, void *o, int64_t ldq, int64_t ldk, int64_t ldv,
+                           int64_t ldo, int batch, int seq, int heads, float scale, const void *zero_page,
+                           const unsigned *only_flagged, void *stream, const char *who);
+
+// bytes of workspace sp_attn_spatial_long_f16 needs: one word per 256 query rows of every (batch item, head)
+extern "C" int64_t sp_attn_long_ws_bytes(int batch, int seq, int heads) {
+  if (batch <= 0 || seq <= 0 || heads <= 0) return 0;
+  return (int64_t)batch * heads * ((seq + LONG_ROWS - 1) / LONG_ROWS) * (int64_t)sizeof(unsigned);
+}
+
+// Spatial self-attention, same contract as sp_attn_spatial_f16 and the same results to fp16 rounding, through the
+// frozen-reference kernel where it applies (seq >= 4096 and a multiple of 256) and through sp_attn_spatial_f16's kernel
+// otherwise.  `workspace` (>= sp_attn_long_ws_bytes, 4-byte aligned, private to this call until it completes on
+// `stream`) receives the per-block flag words; it is zeroed on the stream by this call.
+extern "C" int sp_attn_spatial_long_f16(const void *q, const void *k, const void *v, void *o, int64_t ldq, int64_t ldk,
+                                        int64_t ldv, int64_t ldo, int batch, int seq, int heads, float scale,
+                                        const void *zero_page, void *workspace, int64_t workspace_bytes, void *stream) {
+  SP_REQUIRE(q && k && v && o && zero_page, "sp_attn_spatial_long_f16: null pointer");
+  SP_REQUIRE(batch > 0 && seq > 0 && heads > 0, "sp_attn_spatial_long_f16: batch/seq/heads must be positive");
+  if (!(seq >= 4096 && seq % LONG_ROWS == 0))
+    return sp_attn_spatial_launch(q, k, v, o, ldq, ldk, ldv, ldo, batch, seq, heads, scale, zero_page, nullptr, stream,
+                                  "sp_attn_spatial_long_f16");
+  SP_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0,
+             "sp_attn_spatial_long_f16: strides must be multiples of 8");
+  SP_REQUIRE((int64_t)batch * heads <= 65535, "sp_attn_spatial_long_f16: batch*heads too large");
+  const int64_t need = sp_attn_long_ws_bytes(batch, seq, heads);
+  SP_REQUIRE(workspace && ((uintptr_t)workspace & 3) == 0 && workspace_bytes >= need,
+             "sp_attn_spatial_long_f16: workspace of %lld bytes, need %lld (4-byte aligned)", (long long)workspace_bytes,
+             (long long)need);
+  // the LDS-DMA pieces carry 32-bit lane offsets from the tile's base: 64 rows of K / V must fit
+  SP_REQUIRE(64 * ldk * 2 < (1ll << 31) && 64 * ldv * 2 < (1ll << 31), "sp_attn_spatial_long_f16: row stride too large");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned *flags = (unsigned *)workspace;
+  if (hipMemsetAsync(flags, 0, (size_t)need, s) != hipSuccess) {
+    (void)hipGetLastError();
+    sp_set_error("sp_attn_spatial_long_f16: hipMemsetAsync of the flag words failed");
+    return SP_ELAUNCH;
+  }
+  SP_CLEAR_STALE_ERROR();
+  hipLaunchKernelGGL(attn_long_kernel<LONG_QB>, dim3(seq / LONG_ROWS, batch * heads), dim3(256), 0, s, (const f16 *)q,
+                     (const f16 *)k, (const f16 *)v, (f16 *)o, ldq, ldk, ldv, ldo, seq, heads, scale * 1.4426950408889634f,
+                     flags);
+  SP_CHECK_LAUNCH("sp_attn_spatial_long_f16");
+  // second look at the blocks whose reference turned out too low: the ordinary kernel, flagged blocks only
+  return sp_attn_spatial_launch(q, k, v, o, ldq, ldk, ldv, ldo, batch, seq, heads, scale, zero_page, flags, stream,
+                                "sp_attn_spatial_long_f16(second pass)");
+}

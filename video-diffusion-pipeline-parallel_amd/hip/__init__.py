@@ -56,6 +56,8 @@ SIGNATURES = {
     "sp_layernorm_f16": (_I, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _F, _P]),
     "sp_ln_stats_f16": (_I, [_P, _P, _L, _P, _P, _L, _I, _F, _P]),
     "sp_attn_spatial_f16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _P]),
+    "sp_attn_long_ws_bytes": (_L, [_I, _I, _I]),
+    "sp_attn_spatial_long_f16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _P, _L, _P]),
     "sp_attn_fp8_ws_bytes": (_L, [_I, _I, _I]),
     "sp_attn_spatial_fp8": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _L, _P, _P]),
     "sp_attn_temporal_f16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _L, _I, _F, _P, _P]),

@@ -127,12 +127,16 @@ class SVDUNetHIP:
     FP8_MIN_SEQ = 1024
     # few-row levels whose long-K contractions may be split over K (csrc/gemm.hip::SPLITK_MAX_ROWS)
     SPLITK_MAX_ROWS = 6144
+    # rows this long go through the frozen-reference attention kernel (csrc/attention_long.hip; tools/bench_attn_long.py:
+    # 1.05-1.09x of the ordinary kernel at 9,216 tokens, 0.9-0.97x at 4,096); VDPP_LONG_ATTN=0 turns it off
+    LONG_ATTENTION_MIN_SEQ = 8192
 
     def __init__(self, cfg: UNetConfig, state_dict: dict, device, *, fp8_attention: bool | None = None):
         """``fp8_attention``: run the spatial self-attention on fp8-e4m3 MFMA (BASELINE config 5: "SVD-XT ... with
         fp8 MFMA attention path"); default off, or ``VDPP_FP8_ATTN=1``.  Everything else stays fp16."""
         self.cfg = cfg
         self.fp8_attention = (os.environ.get("VDPP_FP8_ATTN") == "1") if fp8_attention is None else bool(fp8_attention)
+        self.long_attention = os.environ.get("VDPP_LONG_ATTN", "1") != "0"
         self.device = dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("SVDUNetHIP runs on an MI355X HIP device only (no CPU fallback)")
@@ -191,6 +195,7 @@ class SVDUNetHIP:
         self._sk_ws = {}
         self._pos_cache = {}
         self._fp8_ws = {}
+        self._long_ws = {}
 
     def release_stream_state(self) -> None:
         """Drop every per-stream scratch buffer (GroupNorm partials, split-K slabs, fp8 operands).  They are keyed by
@@ -201,6 +206,7 @@ class SVDUNetHIP:
         self._gn_ws = None
         self._sk_ws = {}
         self._fp8_ws = {}
+        self._long_ws = {}
 
     # ------------------------------------------------------------------ weight packing
     def _reg_temb(self, sd, p):
@@ -404,6 +410,14 @@ class SVDUNetHIP:
                 ws = self._fp8_ws[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
             ops.attn_spatial_fp8(q, k, v, o, ws, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=r.b * r.f, seq=r.hw,
                                  heads=heads)
+        elif self.long_attention and r.hw >= self.LONG_ATTENTION_MIN_SEQ and r.hw % 256 == 0:
+            need = ops.attn_long_ws_bytes(r.b * r.f, r.hw, heads)
+            skey = torch.cuda.current_stream(self.device).cuda_stream     # one set of flag words per HIP stream
+            ws = self._long_ws.get(skey)
+            if ws is None or ws.numel() < need:
+                ws = self._long_ws[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            ops.attn_spatial_long(q, k, v, o, ws, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=r.b * r.f, seq=r.hw,
+                                  heads=heads)
         else:
             ops.attn_spatial(q, k, v, o, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=r.b * r.f, seq=r.hw,
                              heads=heads)
