@@ -596,6 +596,22 @@ def test_benchmark_shape_two_kernel_routes_agree_and_are_deterministic(monkeypat
     upd_a, upd_c = (a.float() - lat.float()).cpu(), (c.float() - lat.float()).cpu()
     err = rel_l2(upd_c, upd_a)
     assert err <= 5e-3, f"kernel routes disagree at the benchmark shape: rel_l2={err:.3e}"
+    # and with the level-0 attention through the frozen-reference kernel (opt-in: SVDUNetHIP(long_attention=True)):
+    # another softmax reference and summation order, same arithmetic
+    assert not model.unet.long_attention
+    model.unet.long_attention = True
+    try:
+        seen = []
+        orig = ops.attn_spatial_long
+        monkeypatch.setattr(ops, "attn_spatial_long", lambda *a, **k: (seen.append(k["seq"]), orig(*a, **k))[1])
+        d = model(lat, 0)
+        e = model(lat, 0)
+    finally:
+        model.unet.long_attention = False
+    assert seen and set(seen) == {72 * 128}, f"frozen-reference kernel not on the level-0 rows: {seen}"
+    assert torch.equal(d, e), "two launches with long_attention differ"
+    err = rel_l2((d.float() - lat.float()).cpu(), upd_a)
+    assert err <= 2e-3, f"long_attention changes the step at the benchmark shape: rel_l2={err:.3e}"
 
 
 def test_config5_shape_fp8_attention_agrees_with_fp16():

@@ -11,7 +11,7 @@ from vdpp_amd.hip import ops
 from vdpp_amd.models.svd_unet import StableVideoUNet
 dev = torch.device("cuda:0")
 batch = int(os.environ.get("BATCH", 2))
-model = StableVideoUNet.from_random_init(StableVideoUNet._default_timestep_schedule(25), seed=0, device=dev)
+model = StableVideoUNet.from_random_init(StableVideoUNet._default_timestep_schedule(25), seed=0, device=dev, long_attention=True)
 torch.manual_seed(42)
 model.set_dummy_conditioning(batch, 14, 72, 128, dev)
 lat = torch.randn(batch, 4, 14, 72, 128, device=dev, dtype=torch.float16) * model.init_noise_sigma

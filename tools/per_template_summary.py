@@ -37,11 +37,14 @@ for t in bench["roofline"]["per_template"]:
     tot_ms += ms; tot_fl += t["tflop"]
     print(f"{t['kernel']:52s} {calls / forwards:12.1f} {ms:8.3f} {t['tflop']:10.4f} {tf:8.1f} {tf / PEAK:9.3f}")
 print(f"{'all contraction kernels':52s} {'':12s} {tot_ms:8.3f} {tot_fl:10.4f} {tot_fl / (tot_ms / 1e3):8.1f} {tot_fl / (tot_ms / 1e3) / PEAK:9.3f}")
-for name, key, fl in (("attn_spatial_kernel", "attn_spatial", None),):
+for name, key, bkey in (("attn_long_kernel", "attn_long_kernel", "roofline_attention"),
+                        ("attn_spatial_kernel", "attn_spatial_kernel", "roofline_attention_short_rows")):
     r = [v for k, v in rows.items() if key in k]
-    if r and "roofline_attention" in bench:
+    if bkey not in bench and bkey == "roofline_attention_short_rows" and "attn_spatial" in bench.get("roofline_attention", {}).get("kernel", ""):
+        bkey = "roofline_attention"
+    if r and bkey in bench and key.split("_kernel")[0] in bench[bkey]["kernel"]:
         ms = sum(float(x["TotalDurationNs"]) for x in r) / 1e6 / forwards
-        ra = bench["roofline_attention"]
+        ra = bench[bkey]
         flops = ra["achieved"] * 1e12 * ra["avg_launch_us"] * 1e-6 * ra["launches_per_forward"]
         print(f"{name:52s} {sum(float(x['Calls']) for x in r) / forwards:12.1f} {ms:8.3f} {flops / 1e12:10.4f} "
               f"{flops / 1e12 / (ms / 1e3):8.1f} {flops / 1e12 / (ms / 1e3) / PEAK:9.3f}")

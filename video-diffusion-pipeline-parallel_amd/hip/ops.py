@@ -210,7 +210,8 @@ def attn_long_ws_bytes(batch, seq, heads) -> int:
 def attn_spatial_long(q, k, v, o, workspace, *, ldq, ldk, ldv, ldo, batch, seq, heads, scale=0.125):
     """Spatial attention through the frozen-reference kernel for long rows (csrc/attention_long.hip; other shapes go to
     the ordinary kernel inside the call); `workspace`: tensor of >= attn_long_ws_bytes() bytes (flag words)."""
-    with _Timed("attn_spatial", 4.0 * batch * heads * seq * seq * 64):
+    long_rows = seq >= 4096 and seq % 256 == 0            # the call's own rule; other shapes run the ordinary kernel
+    with _Timed("attn_spatial_long" if long_rows else "attn_spatial", 4.0 * batch * heads * seq * seq * 64):
         _check(load().sp_attn_spatial_long_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), ldq, ldk, ldv, ldo,
                                                batch, seq, heads, scale, zero_page(o.device).data_ptr(),
                                                workspace.data_ptr(), workspace.numel() * workspace.element_size(),

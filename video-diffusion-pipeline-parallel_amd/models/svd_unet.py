@@ -149,11 +149,12 @@ class StableVideoUNet(nn.Module):
 
     @classmethod
     def from_random_init(cls, timesteps: Sequence[int], *, config: UNetConfig | None = None, seed: int = 0,
-                         device="cuda", fp8_attention: bool | None = None) -> "StableVideoUNet":
+                         device="cuda", fp8_attention: bool | None = None,
+                         long_attention: bool | None = None) -> "StableVideoUNet":
         """Random weights of the exact SVD architecture (benchmarks / tests; no checkpoint needed)."""
         cfg = config or UNetConfig.svd()
         sd = random_state_dict(cfg, seed=seed, device=device, dtype=torch.float16)
-        unet = SVDUNetHIP(cfg, sd, device, fp8_attention=fp8_attention)
+        unet = SVDUNetHIP(cfg, sd, device, fp8_attention=fp8_attention, long_attention=long_attention)
         del sd
         return cls(unet=unet, timesteps=timesteps)
 

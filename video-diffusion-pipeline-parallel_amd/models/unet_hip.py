@@ -127,16 +127,21 @@ class SVDUNetHIP:
     FP8_MIN_SEQ = 1024
     # few-row levels whose long-K contractions may be split over K (csrc/gemm.hip::SPLITK_MAX_ROWS)
     SPLITK_MAX_ROWS = 6144
-    # rows this long go through the frozen-reference attention kernel (csrc/attention_long.hip; tools/bench_attn_long.py:
-    # 1.05-1.09x of the ordinary kernel at 9,216 tokens, 0.9-0.97x at 4,096); VDPP_LONG_ATTN=0 turns it off
+    # with long_attention, rows this long go through the frozen-reference kernel (csrc/attention_long.hip;
+    # tools/bench_attn_long.py: 1.03-1.09x of the ordinary kernel at 9,216 tokens, 0.9-0.97x at 4,096)
     LONG_ATTENTION_MIN_SEQ = 8192
 
-    def __init__(self, cfg: UNetConfig, state_dict: dict, device, *, fp8_attention: bool | None = None):
+    def __init__(self, cfg: UNetConfig, state_dict: dict, device, *, fp8_attention: bool | None = None,
+                 long_attention: bool | None = None):
         """``fp8_attention``: run the spatial self-attention on fp8-e4m3 MFMA (BASELINE config 5: "SVD-XT ... with
-        fp8 MFMA attention path"); default off, or ``VDPP_FP8_ATTN=1``.  Everything else stays fp16."""
+        fp8 MFMA attention path"); default off, or ``VDPP_FP8_ATTN=1``.  Everything else stays fp16.
+        ``long_attention``: level-0 rows through the frozen-reference kernel; default off, or ``VDPP_LONG_ATTN=1``.
+        Same results; it is faster while no query meets, far from its own tokens, a key that scores 11 nats above
+        everything near them, and up to 2x slower on the rows where that happens all the time (DESIGN.md section 3;
+        ``tools/long_attn_flags.py`` counts the cases on a given set of weights)."""
         self.cfg = cfg
         self.fp8_attention = (os.environ.get("VDPP_FP8_ATTN") == "1") if fp8_attention is None else bool(fp8_attention)
-        self.long_attention = os.environ.get("VDPP_LONG_ATTN", "1") != "0"
+        self.long_attention = (os.environ.get("VDPP_LONG_ATTN") == "1") if long_attention is None else bool(long_attention)
         self.device = dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("SVDUNetHIP runs on an MI355X HIP device only (no CPU fallback)")
