@@ -144,6 +144,13 @@ size_t sp_groupnorm_ws_bytes(int instances, int64_t rows, int c, int groups);
 int sp_groupnorm_f16(const void *x, const float *gamma, const float *beta, void *y, int instances,
                      int64_t rows, int c, int groups, float eps, int fuse_silu, void *ws,
                      size_t ws_bytes, void *stream);
+/* The same with x a column slice of a wider row-major tensor: rows of ldx halves (ldx >= C, a multiple of 8), the C
+ * channels at the head of each; y stays dense.  (The skip tensors of the down path live inside the buffers the up path
+ * would otherwise build with torch.cat -- unet_spatio_temporal_condition.py up blocks -- so the norms that read them
+ * in the down path see strided rows.) */
+int sp_groupnorm_ld_f16(const void *x, int64_t ldx, const float *gamma, const float *beta, void *y, int instances,
+                        int64_t rows, int c, int groups, float eps, int fuse_silu, void *ws,
+                        size_t ws_bytes, void *stream);
 
 /* LayerNorm over the last dim (torch.nn.LayerNorm in BasicTransformerBlock /
  * TemporalBasicTransformerBlock).  Optional pre-add of a per-frame vector

@@ -261,6 +261,31 @@ def test_groupnorm(inst, rows, c, silu):
     check(y, ref)
 
 
+@pytest.mark.parametrize("inst,rows,c,extra", [(2, 9216, 320, 320), (1, 14 * 2304, 640, 1280), (14, 576, 1280, 640),
+                                                (14, 144, 2560, 8), (3, 1000, 960, 64)])
+def test_groupnorm_strided_input(inst, rows, c, extra):
+    """sp_groupnorm_ld_f16: x is the right-hand column slice of a wider buffer (the skip half of a concatenation buffer:
+    rows of c + extra halves).  Every path (three-launch with and without the finalize kernel, single-launch) must give
+    exactly what it gives on a dense copy, and must not touch the other columns' meaning (they hold huge values)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(c + rows + extra)
+    x = h(torch.randn(inst * rows, c, generator=g) * 2 + 0.7)
+    gamma = torch.randn(c, generator=g); beta = torch.randn(c, generator=g)
+    wide = torch.full((inst * rows, c + extra), 3.0e4, dtype=torch.float16, device=DEV)
+    wide[:, extra:] = x.half().to(DEV)
+    ws = torch.empty(ops.groupnorm_ws_bytes(inst, rows, c, 32), dtype=torch.uint8, device=DEV)
+    kw = dict(instances=inst, rows=rows, c=c, groups=32, eps=1e-6, silu=True, ws=ws)
+    y_dense = torch.empty(inst * rows, c, dtype=torch.float16, device=DEV)
+    ops.groupnorm(x.half().to(DEV), gamma.to(DEV), beta.to(DEV), y_dense, **kw)
+    y = torch.empty_like(y_dense)
+    ops.groupnorm(wide[:, extra:], gamma.to(DEV), beta.to(DEV), y, ldx=c + extra, **kw)
+    assert torch.equal(y, y_dense)
+    ref = F.silu(F.group_norm(x.view(inst, rows, c).permute(0, 2, 1), 32, gamma, beta, eps=1e-6)).permute(0, 2, 1)
+    check(y.view(inst, rows, c), ref)
+    with pytest.raises(ValueError):                       # the pitch has to be the tensor's own
+        ops.groupnorm(wide[:, extra:], gamma.to(DEV), beta.to(DEV), y, ldx=c, **kw)
+
+
 @pytest.mark.parametrize("inst,rows,c", [(2, 9216, 320), (1, 14 * 2304, 640), (14, 576, 1280), (14, 144, 2560),
                                           (3, 1000, 960), (1, 2016, 1280)])
 def test_groupnorm_large_mean_small_variance(inst, rows, c):

@@ -16,7 +16,7 @@ namespace {
 __host__ __device__ inline int gn_rows_per_iter(int oc) { int p = 512 / oc; return p < 1 ? 1 : p; }
 
 __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ part, int64_t rows,
-                                int c, int groups, int splits, int64_t per) {
+                                int c, int groups, int splits, int64_t per, int64_t ldx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *sh = (float *)smem;                      // [P][C][2], then [parts][groups][2] behind it
   const int oc = c >> 3;
@@ -30,14 +30,14 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
   const int cpg = c / groups;
   {
     // the group's first element of the instance's first row, for each of this thread's 8 channels
-    const f16 *row0 = x + ((int64_t)inst * rows) * c;
+    const f16 *row0 = x + ((int64_t)inst * rows) * ldx;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       s[e] = ss[e] = 0.f;
       ref[e] = o < oc ? (float)row0[((o * 8 + e) / cpg) * cpg] : 0.f;
     }
   }
-  const f16 *base = x + ((int64_t)inst * rows) * c + o * 8;
+  const f16 *base = x + ((int64_t)inst * rows) * ldx + o * 8;
   if (pr < P) {
     // batches of four independent 16-byte loads per thread, double-buffered: the next batch is in flight while this one
     // is accumulated (a block has only ~10 row-iterations: without the overlap it is a chain of exposed round trips)
@@ -52,11 +52,11 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
     if (r + 3 * (int64_t)P < r1) {
       f16x8 va[4], vb[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) va[u] = *(const f16x8 *)(base + (r + (int64_t)u * P) * c);
+      for (int u = 0; u < 4; ++u) va[u] = *(const f16x8 *)(base + (r + (int64_t)u * P) * ldx);
       r += step;
       for (; r + 3 * (int64_t)P < r1; r += step) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) vb[u] = *(const f16x8 *)(base + (r + (int64_t)u * P) * c);
+        for (int u = 0; u < 4; ++u) vb[u] = *(const f16x8 *)(base + (r + (int64_t)u * P) * ldx);
         acc4(va);
 #pragma unroll
         for (int u = 0; u < 4; ++u) va[u] = vb[u];
@@ -64,7 +64,7 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
       acc4(va);
     }
     for (; r < r1; r += P) {
-      const f16x8 v = *(const f16x8 *)(base + r * c);
+      const f16x8 v = *(const f16x8 *)(base + r * ldx);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float f = (float)v[e] - ref[e]; s[e] += f; ss[e] += f * f; }
     }
@@ -105,7 +105,7 @@ __global__ void gn_stats_kernel(const f16 *__restrict__ x, float *__restrict__ p
 // one block per instance: fold the per-split partials into mean / rstd (fixed order, fp64)
 __global__ __launch_bounds__(1024) void gn_finalize_kernel(const f16 *__restrict__ x, const float *__restrict__ part,
                                                            float *__restrict__ stats, int64_t rows, int c,
-                                                           int groups, int splits, float eps) {
+                                                           int groups, int splits, float eps, int64_t ldx) {
   __shared__ double sh[1024 * 2];
   const int tid = threadIdx.x, inst = blockIdx.x;
   const int slices = 1024 / groups;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const f16 *__restrict
     const double cnt = (double)rows * cpg;
     const double dmean = a / cnt;                        // mean of (x - ref): of the order of the standard deviation
     double var = b / cnt - dmean * dmean; if (var < 0.0) var = 0.0;
-    const double ref = (double)(float)x[((int64_t)inst * rows) * c + tid * cpg];
+    const double ref = (double)(float)x[((int64_t)inst * rows) * ldx + tid * cpg];
     stats[((int64_t)inst * groups + tid) * 2] = (float)(ref + dmean);
     stats[((int64_t)inst * groups + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
@@ -145,7 +145,7 @@ __global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restri
                                 const float *__restrict__ part, int splits, float eps,
                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                 f16 *__restrict__ y, int64_t rows, int c, int groups, int silu,
-                                int64_t rows_per_block) {
+                                int64_t rows_per_block, int64_t ldx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int oc = c >> 3;
   const int P = gn_rows_per_iter(oc);
@@ -179,7 +179,7 @@ __global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restri
       const double cnt = (double)rows * cpg;
       const double dmean = a / cnt;
       double var = b / cnt - dmean * dmean; if (var < 0.0) var = 0.0;
-      const double ref = (double)(float)x[((int64_t)inst * rows) * c + tid * cpg];
+      const double ref = (double)(float)x[((int64_t)inst * rows) * ldx + tid * cpg];
       stl[tid * 2] = (float)(ref + dmean);
       stl[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
@@ -199,7 +199,7 @@ __global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restri
   }
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
-  const f16 *xb = x + ((int64_t)inst * rows) * c + o * 8;
+  const f16 *xb = x + ((int64_t)inst * rows) * ldx + o * 8;
   f16 *yb = y + ((int64_t)inst * rows) * c + o * 8;
   auto emit4 = [&](const f16x8 (&v)[4], int64_t rr) {
 #pragma unroll
@@ -219,12 +219,12 @@ __global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restri
   if (r + 3 * (int64_t)P < r1) {       // batches of four loads per thread, the next batch in flight while this one is written
     f16x8 va[4], vb[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) va[u] = *(const f16x8 *)(xb + (r + (int64_t)u * P) * c);
+    for (int u = 0; u < 4; ++u) va[u] = *(const f16x8 *)(xb + (r + (int64_t)u * P) * ldx);
     int64_t rp = r;
     r += step;
     for (; r + 3 * (int64_t)P < r1; r += step) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) vb[u] = *(const f16x8 *)(xb + (r + (int64_t)u * P) * c);
+      for (int u = 0; u < 4; ++u) vb[u] = *(const f16x8 *)(xb + (r + (int64_t)u * P) * ldx);
       emit4(va, rp);
       rp = r;
 #pragma unroll
@@ -233,7 +233,7 @@ __global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restri
     emit4(va, rp);
   }
   for (; r < r1; r += P) {
-    const f16x8 v = *(const f16x8 *)(xb + r * c);
+    const f16x8 v = *(const f16x8 *)(xb + r * ldx);
     f16x8 w;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -253,13 +253,14 @@ __global__ void gn_apply_kernel(const f16 *__restrict__ x, const float *__restri
 template <int VEC, int MAXIT>
 __global__ __launch_bounds__(512) void gn_fused_kernel(const f16 *__restrict__ x, const float *__restrict__ gamma,
                                                        const float *__restrict__ beta, f16 *__restrict__ y,
-                                                       int64_t rows, int c, int groups, float eps, int silu) {
+                                                       int64_t rows, int c, int groups, float eps, int silu,
+                                                       int64_t ldx) {
   typedef _Float16 hv __attribute__((ext_vector_type(VEC)));
   __shared__ float red[2 * 8 + 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int inst = blockIdx.x / groups, g = blockIdx.x - inst * groups;
   const int cpg = c / groups, vpr = cpg / VEC;               // vectors per row
-  const f16 *xb = x + (int64_t)inst * rows * c + (int64_t)g * cpg;
+  const f16 *xb = x + (int64_t)inst * rows * ldx + (int64_t)g * cpg;
   f16 *yb = y + (int64_t)inst * rows * c + (int64_t)g * cpg;
   // thread -> (vector q of the row, row rr of every pass of RP rows): one division per thread, 32-bit addressing
   const int rp = 512 / vpr;                                  // rows per pass
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(const f16 *__restrict__ x
     const int r = rr + it * rp;
     live[it] = act && r < nrows;
     if (live[it]) {
-      v[it] = *(const hv *)(xb + (int64_t)r * c + q * VEC);
+      v[it] = *(const hv *)(xb + (int64_t)r * ldx + q * VEC);
     } else {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) v[it][e] = (f16)0.f;
@@ -530,10 +531,23 @@ extern "C" size_t sp_groupnorm_ws_bytes(int instances, int64_t rows, int c, int 
   return (size_t)instances * (512 + 1) * groups * 2 * sizeof(float);
 }
 
+extern "C" int sp_groupnorm_ld_f16(const void *x, int64_t ldx, const float *gamma, const float *beta, void *y,
+                                   int instances, int64_t rows, int c, int groups, float eps,
+                                   int fuse_silu, void *ws, size_t ws_bytes, void *stream);
+
 extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *beta, void *y,
                                 int instances, int64_t rows, int c, int groups, float eps,
                                 int fuse_silu, void *ws, size_t ws_bytes, void *stream) {
+  return sp_groupnorm_ld_f16(x, c, gamma, beta, y, instances, rows, c, groups, eps, fuse_silu, ws, ws_bytes, stream);
+}
+
+// x: [instances * rows][ldx] with the C normalised channels at the head of every row (a column slice of a wider
+// tensor: the skip half of a concatenation buffer); y stays dense [instances * rows][C]
+extern "C" int sp_groupnorm_ld_f16(const void *x, int64_t ldx, const float *gamma, const float *beta, void *y,
+                                   int instances, int64_t rows, int c, int groups, float eps,
+                                   int fuse_silu, void *ws, size_t ws_bytes, void *stream) {
   SP_REQUIRE(x && y && ws, "sp_groupnorm_f16: null pointer");
+  SP_REQUIRE(ldx >= c && ldx % 8 == 0, "sp_groupnorm_f16: ldx=%lld must be a multiple of 8 and >= C=%d", (long long)ldx, c);
   SP_REQUIRE(instances > 0 && rows > 0, "sp_groupnorm_f16: instances/rows must be positive");
   SP_REQUIRE(c % 8 == 0 && c >= 8 && c <= 4096, "sp_groupnorm_f16: C=%d must be a multiple of 8 in [8,4096]", c);
   SP_REQUIRE(groups > 0 && groups <= 64 && c % groups == 0, "sp_groupnorm_f16: groups=%d invalid for C=%d", groups, c);
@@ -551,13 +565,13 @@ extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *
       SP_CLEAR_STALE_ERROR();
       if (rows <= 16 * rp) {
         hipLaunchKernelGGL((gn_fused_kernel<8, 16>), dim3(instances * groups), dim3(512), 0, fs, (const f16 *)x, gamma,
-                           beta, (f16 *)y, rows, c, groups, eps, fuse_silu);
+                           beta, (f16 *)y, rows, c, groups, eps, fuse_silu, ldx);
         SP_CHECK_LAUNCH("sp_groupnorm_f16(fused)");
         return SP_OK;
       }
       if (rows <= 20 * rp) {
         hipLaunchKernelGGL((gn_fused_kernel<8, 20>), dim3(instances * groups), dim3(512), 0, fs, (const f16 *)x, gamma,
-                           beta, (f16 *)y, rows, c, groups, eps, fuse_silu);
+                           beta, (f16 *)y, rows, c, groups, eps, fuse_silu, ldx);
         SP_CHECK_LAUNCH("sp_groupnorm_f16(fused)");
         return SP_OK;
       }
@@ -573,7 +587,7 @@ extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *
   const size_t lds = ((size_t)P * c * 2 + (size_t)(threads / groups) * groups * 2) * sizeof(float);
   SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(gn_stats_kernel, dim3(instances, splits), dim3(threads), lds, s, (const f16 *)x,
-                     (float *)ws, rows, c, groups, splits, per);
+                     (float *)ws, rows, c, groups, splits, per, ldx);
   SP_CHECK_LAUNCH("sp_groupnorm_f16(stats)");
   int64_t blocks_y = (2048 + instances - 1) / instances;
   int64_t maxb = (rows + 16 * P - 1) / (16 * P);
@@ -590,11 +604,11 @@ extern "C" int sp_groupnorm_f16(const void *x, const float *gamma, const float *
   const bool fold_in_apply = splits <= 128;
   if (!fold_in_apply)
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(instances), dim3(1024), 0, s, (const f16 *)x, (const float *)ws, stats,
-                       rows, c, groups, splits, eps);
+                       rows, c, groups, splits, eps, ldx);
   const size_t lds_apply = fold_in_apply ? (size_t)(threads / groups) * groups * 2 * sizeof(double) + groups * 2 * sizeof(float) : 0;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(instances, (unsigned)blocks_y), dim3(threads), lds_apply, s,
                      (const f16 *)x, (const float *)stats, fold_in_apply ? (const float *)ws : (const float *)nullptr, splits,
-                     eps, gamma, beta, (f16 *)y, rows, c, groups, fuse_silu, rpb);
+                     eps, gamma, beta, (f16 *)y, rows, c, groups, fuse_silu, rpb, ldx);
   SP_CHECK_LAUNCH("sp_groupnorm_f16(apply)");
   return SP_OK;
 }

@@ -53,6 +53,7 @@ SIGNATURES = {
     "sp_sinusoid_f16": (_I, [_P, _P, _I, _I, _P]),
     "sp_groupnorm_ws_bytes": (_Z, [_I, _L, _I, _I]),
     "sp_groupnorm_f16": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _Z, _P]),
+    "sp_groupnorm_ld_f16": (_I, [_P, _L, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _Z, _P]),
     "sp_layernorm_f16": (_I, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _F, _P]),
     "sp_ln_stats_f16": (_I, [_P, _P, _L, _P, _P, _L, _I, _F, _P]),
     "sp_attn_spatial_f16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _P]),

@@ -170,12 +170,14 @@ def groupnorm_ws_bytes(instances, rows, c, groups) -> int:
     return int(load().sp_groupnorm_ws_bytes(instances, rows, c, groups))
 
 
-def groupnorm(x, gamma, beta, y, *, instances, rows, c, groups, eps, silu, ws):
+def groupnorm(x, gamma, beta, y, *, instances, rows, c, groups, eps, silu, ws, ldx=None):
+    """``ldx``: halves between consecutive rows of ``x`` when it is a column slice of a wider tensor (default: dense)."""
     # algorithmic bytes: statistics pass reads x, apply pass reads x and writes y (the single-launch path reads once)
     with _Timed("groupnorm", 0.0, 3 * 2.0 * instances * rows * c):
-        _check(load().sp_groupnorm_f16(_f16(x, "x").data_ptr(), _ptr(gamma), _ptr(beta), _f16(y, "y").data_ptr(),
-                                       instances, rows, c, groups, eps, int(silu), ws.data_ptr(),
-                                       ws.numel() * ws.element_size(), _stream()), "sp_groupnorm_f16")
+        ldx = int(c if ldx is None else ldx)
+        _check(load().sp_groupnorm_ld_f16(_rows(x, "x", ldx).data_ptr(), ldx, _ptr(gamma), _ptr(beta),
+                                          _f16(y, "y").data_ptr(), instances, rows, c, groups, eps, int(silu),
+                                          ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), "sp_groupnorm_f16")
     return y
 
 

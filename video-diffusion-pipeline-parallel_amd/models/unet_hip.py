@@ -183,7 +183,7 @@ class SVDUNetHIP:
             for j in range(layers):
                 skip = in_ch if j == layers - 1 else out_ch
                 rin = prev if j == 0 else out_ch
-                res.append(self._resblock(sd, f"up_blocks.{i}.resnets.{j}", rin + skip, out_ch, 1e-6))
+                res.append(dict(self._resblock(sd, f"up_blocks.{i}.resnets.{j}", rin + skip, out_ch, 1e-6), cx=rin))
                 if attn:
                     att.append(self._transformer(sd, f"up_blocks.{i}.attentions.{j}", out_ch))
             us = _Dense.conv3x3(sd, f"up_blocks.{i}.upsamplers.0.conv", dev) if ups else None
@@ -344,12 +344,19 @@ class SVDUNetHIP:
         out = kw.pop("out", None)
         if out is None:
             out = self._buf(m, layer.n_true)
+        elif out.shape != (m, layer.n_true):
+            raise RuntimeError(f"destination {tuple(out.shape)} does not match the contraction's output ({m}, {layer.n_true})")
+        # operands may be column slices of wider row-major buffers (the halves of a concatenation buffer): row pitches
+        # come from the tensors
+        for key, ld in (("res1", "ldr1"), ("res2", "ldr2")):
+            if kw.get(key) is not None:
+                kw.setdefault(ld, kw[key].stride(0))
         n_store = layer.n_true if (layer.n_true != (layer.n // 2 if layer.geglu else layer.n)) else 0
         temporal = (r.f, r.hw) if layer.mode == ops.A_TEMPORAL3 else None
         if layer.colsum is not None and "ln_stats" not in kw:
             raise RuntimeError("this contraction carries a folded LayerNorm: pass ln_stats")
         ops.gemm(a, layer.w, out, m=m, n=layer.n, cin=layer.cin, mode=layer.mode, conv=conv, temporal=temporal,
-                 bias=layer.bias, geglu=layer.geglu, n_store=n_store, ldd=layer.n_true, lda=a.shape[1],
+                 bias=layer.bias, geglu=layer.geglu, n_store=n_store, ldd=out.stride(0), lda=a.stride(0),
                  ln_colsum=layer.colsum, workspace=r.sk_ws if m <= self.SPLITK_MAX_ROWS else None, **kw)
         return out
 
@@ -364,7 +371,7 @@ class SVDUNetHIP:
         inst, rows = (r.b, r.f * r.hw) if temporal else (r.b * r.f, r.hw)
         y = self._buf(x.shape[0], c)
         ops.groupnorm(x, norm.g, norm.b, y, instances=inst, rows=rows, c=c, groups=self.cfg.norm_groups,
-                      eps=norm.eps, silu=silu, ws=r.gn_ws)
+                      eps=norm.eps, silu=silu, ws=r.gn_ws, ldx=x.stride(0))
         return y
 
     def _ln(self, norm: _Norm, x, **kw):
@@ -378,7 +385,8 @@ class SVDUNetHIP:
         return (r.b * r.f, r.h, r.w, ho, wo, stride, ups), ho, wo
 
     # ------------------------------------------------------------------ blocks
-    def _run_resblock(self, r: _Run, p, x):
+    def _run_resblock(self, r: _Run, p, x, out=None):
+        """``out``: where the block's result goes (a half of a concatenation buffer), default a fresh tensor."""
         geom, _, _ = self._conv_geom(r)
         t = self._gn(r, p["n1"], x, temporal=False, silu=True)
         n1 = p["c1"].n
@@ -390,7 +398,7 @@ class SVDUNetHIP:
         t = self._gn(r, p["tn1"], s, temporal=True, silu=True)
         t = self._gemm(r, p["tc1"], t, bias2=r.temb[p["te_t"]:p["te_t"] + p["cout"]], bias2_rows=r.m)
         t = self._gn(r, p["tn2"], t, temporal=True, silu=True)
-        return self._gemm(r, p["tc2"], t, oscale=1.0 - p["alpha"], res1=s, r1scale=1.0)
+        return self._gemm(r, p["tc2"], t, oscale=1.0 - p["alpha"], res1=s, r1scale=1.0, out=out)
 
     def _cross_vec(self, r: _Run, x):
         """to_out(to_v(ctx)) + b_out for the single context token -> fp32 [B][C] (computed by _small_gemvs)."""
@@ -430,7 +438,7 @@ class SVDUNetHIP:
         return self._gemm(r, att["out"], o, bias2=self._cross_vec(r, xvec), bias2_rows=r.f * r.hw, res1=resid,
                           r1scale=1.0, **epi)
 
-    def _run_transformer(self, r: _Run, p, x):
+    def _run_transformer(self, r: _Run, p, x, out=None):
         c, a = p["c"], p["alpha"]
         t = self._gn(r, p["norm"], x, temporal=False, silu=False)
         hs = self._gemm(r, p["pin"], t)
@@ -454,7 +462,7 @@ class SVDUNetHIP:
         # temporal out = ff(..)+ht1 ; blend = a*hs_s + (1-a)*temporal out   (folded into the epilogue)
         mix = self._gemm(r, p["t_ff2"], g, oscale=1.0 - a, res1=ht1, r1scale=1.0 - a, res2=hs_s, r2scale=a)
         del g
-        return self._gemm(r, p["pout"], mix, res1=x, r1scale=1.0)
+        return self._gemm(r, p["pout"], mix, res1=x, r1scale=1.0, out=out)
 
     # ------------------------------------------------------------------ forward
     def forward_rows(self, x_rows, *, b, frames, h, w, t_value, ctx16, added_ids32, euler=None):
@@ -506,35 +514,55 @@ class SVDUNetHIP:
                  frame_ids=torch.arange(frames, dtype=torch.float32, device=dev))
         self._small_gemvs(r)
 
+        # No torch.cat (diffusers' up blocks concatenate the running tensor with a skip in front of every resnet): the
+        # buffer [rows][Cx + Cskip] an up resnet reads is allocated when its skip is PRODUCED in the down path; the skip's
+        # producer writes the right-hand columns in place, and the up path's producer of the running tensor (mid block,
+        # previous resnet / transformer / upsampler) writes the left-hand columns.  Until then the down path keeps
+        # working on the skip through its strided view.
+        cx_pop = [p["cx"] for res, _, _ in self.up for p in res]           # in the order the up path consumes skips
+        cats = []                                                          # in the order the down path produces them
+
+        def skip_dest(rows, cskip):
+            cx = cx_pop[len(cx_pop) - 1 - len(cats)]
+            cats.append(self._buf(rows, cx + cskip))
+            return cats[-1][:, cx:]
+
         geom, _, _ = self._conv_geom(r)
-        x = self._gemm(r, self.conv_in, x_rows, conv=geom)
-        skips = [x]
+        x = self._gemm(r, self.conv_in, x_rows, conv=geom, out=skip_dest(r.m, self.conv_in.n_true))
         for res, att, ds in self.down:
             for j, p in enumerate(res):
-                x = self._run_resblock(r, p, x)
                 if att:
-                    x = self._run_transformer(r, att[j], x)
-                skips.append(x)
+                    x = self._run_resblock(r, p, x)
+                    x = self._run_transformer(r, att[j], x, out=skip_dest(r.m, p["cout"]))
+                else:
+                    x = self._run_resblock(r, p, x, out=skip_dest(r.m, p["cout"]))
             if ds is not None:
                 geom, ho, wo = self._conv_geom(r, stride=2)
-                x = self._gemm(r, ds, x, m=r.b * r.f * ho * wo, conv=geom)
+                m_out = r.b * r.f * ho * wo
+                x = self._gemm(r, ds, x, m=m_out, conv=geom, out=skip_dest(m_out, ds.n_true))
                 r.h, r.w = ho, wo
-                skips.append(x)
+        if len(cats) != len(cx_pop):
+            raise RuntimeError("skip bookkeeping out of step with the up blocks")
+
+        def x_dest():                          # left-hand columns of the buffer the next up resnet reads (None: no more)
+            return cats[-1][:, :cx_pop[len(cx_pop) - len(cats)]] if cats else None
+
         x = self._run_resblock(r, self.mid[0], x)
         x = self._run_transformer(r, self.mid[1], x)
-        x = self._run_resblock(r, self.mid[2], x)
+        self._run_resblock(r, self.mid[2], x, out=x_dest())
         for res, att, us in self.up:
             for j, p in enumerate(res):
-                skip = skips.pop()
-                cat = self._buf(r.m, x.shape[1] + skip.shape[1])
-                ops.concat_channels(x, x.shape[1], skip, skip.shape[1], cat, r.m)
-                x = self._run_resblock(r, p, cat)
-                del cat, skip
+                cat = cats.pop()               # both halves are in place
+                last = j == len(res) - 1 and us is not None
                 if att:
-                    x = self._run_transformer(r, att[j], x)
+                    x = self._run_resblock(r, p, cat)
+                    x = self._run_transformer(r, att[j], x, out=None if last else x_dest())
+                else:
+                    x = self._run_resblock(r, p, cat, out=None if last else x_dest())
+                del cat
             if us is not None:
                 geom, ho, wo = self._conv_geom(r, ups=1)
-                x = self._gemm(r, us, x, m=r.b * r.f * ho * wo, conv=geom)
+                x = self._gemm(r, us, x, m=r.b * r.f * ho * wo, conv=geom, out=x_dest())
                 r.h, r.w = ho, wo
         x = self._gn(r, self.norm_out, x, temporal=False, silu=True)
         geom, _, _ = self._conv_geom(r)
