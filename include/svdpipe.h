@@ -99,6 +99,12 @@ typedef struct sp_gemm_desc {
      few rows and a long K (m <= 6144, K >= 8192: the 3x3 convolutions of the UNet's 2,016-row level, 4,032 rows for a micro-batch of two) are split over K on 256 x 256 tiles,
      fp32 partial sums go here and a second kernel reduces them and applies the epilogue.  NULL = never split. */
   void *workspace; size_t workspace_bytes;
+  /* LayerNorm statistics of the OUTPUT rows, for the next contraction's ln_stats (what a following sp_ln_stats_f16 pass
+     over d would compute, without that pass): ln_out = fp32 [m][2] (mean, rstd = 1/sqrt(var + ln_out_eps)) of the n
+     stored fp16 values of every row.  Needs a whole row per tile: n = 256 or 320, no geglu, no n_store, no Euler tail;
+     the call then runs on the ping-pong kernels (no split-K).  Sums are folded in a fixed order: bit-reproducible.
+     NULL = off. */
+  float *ln_out; float ln_out_eps;
 } sp_gemm_desc;
 
 int sp_gemm_f16(const sp_gemm_desc *desc, void *stream);

@@ -309,6 +309,53 @@ def test_groupnorm_large_mean_small_variance(inst, rows, c):
     check(y, ref)
 
 
+@pytest.mark.parametrize("m,cin,n,extras,offset", [(1000, 320, 320, "", 0.0), (129024, 320, 320, "r", 2.0), (2016, 1280, 320, "r2", 0.0),
+                                                    (5000, 640, 256, "b2", 20.0), (777, 64, 320, "r", 20.0), (64512, 1280, 256, "", 0.0)])
+def test_gemm_output_row_layernorm_statistics(m, cin, n, extras, offset):
+    """sp_gemm_desc.ln_out: the epilogue leaves (mean, rstd) of every stored output row beside the output, what an
+    sp_ln_stats_f16 pass over d would compute (so that the next contraction's folded LayerNorm needs no pass of its
+    own).  Against that pass and against torch on the stored values; residuals, a bias2 row per image, ragged m, rows
+    with a common offset of 20 standard deviations; the output itself must equal the call without ln_out, and two calls
+    must agree bit for bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(m + n + cin)
+    a = h(torch.randn(m, cin, generator=g))
+    w = h(torch.randn(n, cin, generator=g) / math.sqrt(cin))
+    b = torch.randn(n, generator=g) + offset
+    kw = dict(m=m, n=n, cin=cin, bias=b.to(DEV))
+    if "r" in extras:
+        kw.update(res1=h(torch.randn(m, n, generator=g)).half().to(DEV), r1scale=1.0)
+    if "r2" in extras:
+        kw.update(res2=h(torch.randn(m, n, generator=g)).half().to(DEV), r2scale=0.5)
+    if "b2" in extras:
+        rows_per = 1000
+        kw.update(bias2=torch.randn((m + rows_per - 1) // rows_per, n, generator=g).to(DEV), bias2_rows=rows_per)
+    ad, wd = a.half().to(DEV), w.half().to(DEV)
+    plain = torch.empty(m, n, dtype=torch.float16, device=DEV)
+    ops.gemm(ad, wd, plain, **kw)
+    out = torch.empty(m, n, dtype=torch.float16, device=DEV)
+    st = torch.full((m + 1, 2), 7.0, dtype=torch.float32, device=DEV)
+    ops.gemm(ad, wd, out, ln_out=st[:m], ln_out_eps=1e-5, **kw)
+    assert "gemm_pp_kernel" in ops.load().sp_gemm_last_kernel().decode()
+    assert torch.all(st[m] == 7.0)
+    x = out.float().cpu()
+    assert rel_l2(x, plain.float().cpu()) <= 1e-3                    # (another kernel family may have produced `plain`)
+    st2 = torch.empty(m, 2, dtype=torch.float32, device=DEV)
+    ops.ln_stats(out, st2, rows=m, c=n, eps=1e-5)
+    mean, var = x.double().mean(dim=1), x.double().var(dim=1, unbiased=False)
+    want = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-5)], dim=1).float()
+    got = st[:m].cpu()
+    assert torch.allclose(got[:, 0], want[:, 0], rtol=0, atol=2e-4 * max(1.0, abs(offset)))
+    assert torch.allclose(got[:, 1], want[:, 1], rtol=2e-3 if offset else 2e-4)
+    assert torch.allclose(got, st2.cpu(), rtol=2e-3 if offset else 2e-4, atol=2e-4 * max(1.0, abs(offset)))
+    out_b = torch.empty_like(out); st_b = torch.empty(m, 2, dtype=torch.float32, device=DEV)
+    ops.gemm(ad, wd, out_b, ln_out=st_b, ln_out_eps=1e-5, **kw)
+    assert torch.equal(out_b, out) and torch.equal(st_b, st[:m])
+    with pytest.raises(ops.HipKernelError, match="ln_out"):           # a row must fit one tile
+        ops.gemm(ad, h(torch.randn(640, cin, generator=g)).half().to(DEV), torch.empty(m, 640, dtype=torch.float16, device=DEV),
+                 m=m, n=640, cin=cin, ln_out=st_b, ln_out_eps=1e-5)
+
+
 @pytest.mark.parametrize("m,c,n,geglu,route", [(1000, 320, 960, False, 0), (5000, 640, 1920, False, 2), (40000, 320, 2560, True, 3),
                                                (2016, 1280, 3840, False, 0), (3000, 1280, 2560, True, 2), (700, 64, 128, True, 1),
                                                (33000, 640, 1280, False, 3),

@@ -494,6 +494,12 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
   const bool ok256 = d->n % 256 == 0, ok320 = d->n % 320 == 0 && !d->geglu;
   const int route = g_route;
 
+  // ---- output-row LayerNorm statistics live in the ping-pong epilogue (one tile = whole rows)
+  if (a.ln_out) {
+    const int bm = makespan(d->m, d->n, 192, d->n) * 1.06 < makespan(d->m, d->n, 256, d->n) ? 192 : 256;
+    return launch_pp(a, bm, d->n, s);
+  }
+
   // ---- persistent-stream tiles (gemm_ps.hip): linear contractions with several tiles per CU, where launch gap,
   // index setup, first-operand latency and the LDS-staged epilogue of a one-tile workgroup are a large share
   if ((route == 0 || route == 3) && (ok256 || ok320)) {
@@ -625,6 +631,10 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   a.a = (const f16 *)d->a; a.w = (const f16 *)d->w; a.bias = d->bias; a.bias2 = d->bias2;
   a.res1 = (const f16 *)d->res1; a.res2 = (const f16 *)d->res2; a.d = (f16 *)d->d;
   a.ln_stats = d->ln_stats; a.ln_colsum = d->ln_colsum;
+  a.ln_out = d->ln_out; a.ln_out_eps = d->ln_out_eps;
+  if (d->ln_out)
+    SP_REQUIRE((d->n == 256 || d->n == 320) && !d->geglu && d->n_store == 0 && !d->euler_out && d->ln_out_eps > 0.f,
+               "sp_gemm_f16: ln_out needs whole rows per tile (n = 256 or 320, got %d), no geglu / n_store / Euler tail", d->n);
   if (d->euler_out) {
     SP_REQUIRE(d->euler_latent && d->n == 64 && d->n_store == 4 && !d->geglu && !d->res1 && !d->res2 && d->oscale == 1.0f,
                "sp_gemm_f16: the Euler tail belongs to conv_out (n = 64, n_store = 4, no residuals, oscale 1)");

@@ -25,6 +25,8 @@ struct GemmArgs {
   float eul_c_out, eul_c_skip, eul_inv_sigma, eul_dt;
   const float *ln_stats;    // LayerNorm fold: fp32 [m][2] (mean, rstd), or null
   const float *ln_colsum;   // fp32 [n]: row sums of the gamma-scaled weight
+  float *ln_out;            // fp32 [m][2]: (mean, rstd) of the stored output rows, or null (ping-pong kernels, n == BN)
+  float ln_out_eps;
   f16 *d;
   const char *zero;
   int64_t lda, ldr1, ldr2, ldd, hw, bias2_rows, ldb2;

@@ -182,6 +182,34 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
     }
   }
   PP_TRACE(7);
+  // ---- LayerNorm statistics of the rows about to be stored (ln_out; host: one tile spans the whole row, n == BN): every
+  // thread leaves (sum, sum of squares) of its eight final fp16 values in LDS -- the staged tile is in registers by now
+  // -- and one thread per row folds the row's chunks in a fixed order.  fp32 sums over 256 / 320 values.
+  if constexpr (!GEGLU) {
+    if (p.ln_out) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read its part of the tile
+      float2 *part = (float2 *)smem;                                       // [PBM][cpr]
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * NT;
+        if (idx < NCH) {
+          float sm = 0.f, sq = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float f = (float)o[it][e]; sm += f; sq = fmaf(f, f, sq); }
+          part[idx] = make_float2(sm, sq);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid < PBM && mbase + tid < p.m) {
+        float sm = 0.f, sq = 0.f;
+        for (int c = 0; c < cpr; ++c) { const float2 v = part[tid * cpr + c]; sm += v.x; sq += v.y; }
+        const float inv = 1.0f / (float)bno, mean = sm * inv;
+        float var = sq * inv - mean * mean;
+        if (var < 0.f) var = 0.f;
+        *(float2 *)(p.ln_out + (mbase + tid) * 2) = make_float2(mean, rsqrtf(var + p.ln_out_eps));
+      }
+    }
+  }
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int idx = tid + it * NT;

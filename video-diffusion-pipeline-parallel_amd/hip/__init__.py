@@ -36,6 +36,7 @@ class GemmDesc(ctypes.Structure):
         ("euler_sigma", ctypes.c_float), ("euler_sigma_next", ctypes.c_float),
         ("euler_frames", ctypes.c_int), ("euler_hw", ctypes.c_int64),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+        ("ln_out", ctypes.c_void_p), ("ln_out_eps", ctypes.c_float),
     ]
 
 

@@ -82,7 +82,7 @@ def _rows(t: torch.Tensor, name: str, ld: int) -> torch.Tensor:
 def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=None, bias=None,
          bias2=None, bias2_rows=0, ldb2=0, res1=None, r1scale=1.0, res2=None, r2scale=1.0, oscale=1.0,
          geglu=False, n_store=0, ldd=None, ldr1=None, ldr2=None, ln_stats=None, ln_colsum=None, euler=None,
-         workspace=None):
+         workspace=None, ln_out=None, ln_out_eps=1e-5):
     """``out[m][:] = epilogue(sum_taps A_tap @ W^T)``; see ``sp_gemm_desc`` in include/svdpipe.h.
     ``ln_stats`` / ``ln_colsum``: LayerNorm folded into the contraction (``a`` is the UN-normalised tensor)."""
     d = GemmDesc()
@@ -108,8 +108,12 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
         d.euler_ld_eps = int(euler.get("ld_eps", 0))
         d.euler_sigma, d.euler_sigma_next = float(euler["sigma"]), float(euler["sigma_next"])
         d.euler_frames, d.euler_hw = int(euler["frames"]), int(euler["hw"])
-    if workspace is not None:      # fp32 scratch for split-K (few rows, long K); too small a buffer simply disables it
+    if workspace is not None and ln_out is None:   # fp32 scratch for split-K (few rows, long K); too small a buffer simply disables it
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    if ln_out is not None:         # (mean, rstd) of the output rows, for the next contraction's folded LayerNorm
+        if ln_out.dtype != torch.float32 or tuple(ln_out.shape) != (m, 2) or not ln_out.is_contiguous():
+            raise ValueError("ln_out must be a contiguous float32 [m][2] tensor")
+        d.ln_out, d.ln_out_eps = ln_out.data_ptr(), float(ln_out_eps)
     taps = 9 if mode == A_CONV3X3 else 3 if mode == A_TEMPORAL3 else 1
     # algorithmic bytes of this launch: every operand element once (A without tap re-reads), output and residuals once
     a_rows = d.n_img * d.hin * d.win if mode == A_CONV3X3 else m

@@ -342,6 +342,15 @@ class SVDUNetHIP:
     def _gemm(self, r: _Run, layer: _Dense, a, *, m=None, conv=None, **kw):
         m = r.m if m is None else m
         out = kw.pop("out", None)
+        # ``ln_next``: the contraction that will consume this output through a folded LayerNorm.  Where one tile spans a
+        # whole output row (256 / 320 channels: level 0) the epilogue leaves that LayerNorm's (mean, rstd) beside the
+        # output and _ln_stats finds them there instead of reading the tensor again.
+        ln_next = kw.pop("ln_next", None)
+        st = None
+        if ln_next is not None and layer.n_true in (256, 320) and layer.n == layer.n_true and not layer.geglu \
+                and "euler" not in kw:
+            st = torch.empty((m, 2), dtype=torch.float32, device=self.device)
+            kw.update(ln_out=st, ln_out_eps=ln_next.ln_eps)
         if out is None:
             out = self._buf(m, layer.n_true)
         elif out.shape != (m, layer.n_true):
@@ -358,10 +367,15 @@ class SVDUNetHIP:
         ops.gemm(a, layer.w, out, m=m, n=layer.n, cin=layer.cin, mode=layer.mode, conv=conv, temporal=temporal,
                  bias=layer.bias, geglu=layer.geglu, n_store=n_store, ldd=out.stride(0), lda=a.stride(0),
                  ln_colsum=layer.colsum, workspace=r.sk_ws if m <= self.SPLITK_MAX_ROWS else None, **kw)
+        if st is not None:
+            out._row_ln_stats = (st, ln_next.ln_eps)
         return out
 
     def _ln_stats(self, layer: _Dense, x, **kw):
         """(mean, rstd) per row of x for the LayerNorm folded into ``layer``."""
+        have = getattr(x, "_row_ln_stats", None)
+        if have is not None and not kw and have[1] == layer.ln_eps:
+            return have[0]                                # left there by the contraction that produced x
         st = torch.empty((x.shape[0], 2), dtype=torch.float32, device=self.device)
         ops.ln_stats(x, st, rows=x.shape[0], c=x.shape[1], eps=layer.ln_eps, **kw)
         return st
@@ -441,9 +455,9 @@ class SVDUNetHIP:
     def _run_transformer(self, r: _Run, p, x, out=None):
         c, a = p["c"], p["alpha"]
         t = self._gn(r, p["norm"], x, temporal=False, silu=False)
-        hs = self._gemm(r, p["pin"], t)
+        hs = self._gemm(r, p["pin"], t, ln_next=p["s_attn"]["qkv"])
         # --- spatial block
-        hs1 = self._self_attn(r, p["s_attn"], p["s_x"], hs, temporal=False)
+        hs1 = self._self_attn(r, p["s_attn"], p["s_x"], hs, temporal=False, ln_next=p["s_ff1"])
         g = self._gemm(r, p["s_ff1"], hs1, ln_stats=self._ln_stats(p["s_ff1"], hs1))
         hs_s = self._gemm(r, p["s_ff2"], g, res1=hs1, r1scale=1.0)
         del g
@@ -455,9 +469,9 @@ class SVDUNetHIP:
         hmix = self._buf(r.m, c)
         st = self._ln_stats(p["t_fi1"], hs_s, addvec=pe, addvec_rows=r.hw, sum_out=hmix)   # also writes hmix = hs_s + pe
         g = self._gemm(r, p["t_fi1"], hmix, ln_stats=st)
-        ht = self._gemm(r, p["t_fi2"], g, res1=hmix, r1scale=1.0)
+        ht = self._gemm(r, p["t_fi2"], g, res1=hmix, r1scale=1.0, ln_next=p["t_attn"]["qkv"])
         del g, hmix, st
-        ht1 = self._self_attn(r, p["t_attn"], p["t_x"], ht, temporal=True)
+        ht1 = self._self_attn(r, p["t_attn"], p["t_x"], ht, temporal=True, ln_next=p["t_ff1"])
         g = self._gemm(r, p["t_ff1"], ht1, ln_stats=self._ln_stats(p["t_ff1"], ht1))
         # temporal out = ff(..)+ht1 ; blend = a*hs_s + (1-a)*temporal out   (folded into the epilogue)
         mix = self._gemm(r, p["t_ff2"], g, oscale=1.0 - a, res1=ht1, r1scale=1.0 - a, res2=hs_s, r2scale=a)
