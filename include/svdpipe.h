@@ -108,6 +108,9 @@ typedef struct sp_gemm_desc {
 } sp_gemm_desc;
 
 int sp_gemm_f16(const sp_gemm_desc *desc, void *stream);
+/* sizeof(sp_gemm_desc) as the library was built: a binding in another language checks its mirror of the struct against
+ * it once at load time (the Python one does: hip/__init__.py::load). */
+size_t sp_gemm_desc_size(void);
 /* bytes of sp_gemm_desc.workspace this contraction can use (0: it is not a split-K candidate) */
 size_t sp_gemm_workspace_bytes(const sp_gemm_desc *desc);
 

@@ -11,6 +11,7 @@ void sp_set_error(const char *fmt, ...) {
 
 extern "C" const char *sp_last_error(void) { return g_err; }
 extern "C" int sp_version(void) { return 100; }
+extern "C" size_t sp_gemm_desc_size(void) { return sizeof(sp_gemm_desc); }
 
 // Raises a kernel's dynamic-LDS limit once per (kernel, device): the attribute is per device, so a process that
 // launches on a second GPU needs it set there too.  `done` is the caller's per-kernel table (one static per template

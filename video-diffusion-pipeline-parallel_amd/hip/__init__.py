@@ -46,6 +46,7 @@ SIGNATURES = {
     "sp_last_error": (ctypes.c_char_p, []),
     "sp_version": (_I, []),
     "sp_gemm_f16": (_I, [ctypes.POINTER(GemmDesc), _P]),
+    "sp_gemm_desc_size": (_Z, []),
     "sp_gemm_workspace_bytes": (_Z, [ctypes.POINTER(GemmDesc)]),
     "sp_gemm_set_route": (_I, [_I, _I, _I]),
     "sp_gemm_last_kernel": (ctypes.c_char_p, []),
@@ -96,6 +97,9 @@ def load():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if lib.sp_gemm_desc_size() != ctypes.sizeof(GemmDesc):
+            raise RuntimeError(f"GemmDesc mirrors {ctypes.sizeof(GemmDesc)} bytes, the library's sp_gemm_desc has "
+                               f"{lib.sp_gemm_desc_size()}: rebuild the library or update hip/__init__.py")
         _lib = lib
     return _lib
 
