@@ -489,6 +489,22 @@ double makespan(int m, int n, int bm, int bn) {
   return (double)((tiles + 255) / 256) * bm * bn;
 }
 
+// (mean, rstd) of rows whose per-tile (sum, sum of squares) a two-tile contraction left in `part` ([m][tiles][2])
+__global__ __launch_bounds__(256) void ln_part_finalize_kernel(const float *__restrict__ part, float *__restrict__ out, int m,
+                                                               int tiles, int n, float eps) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= m) return;
+  float sm = 0.f, sq = 0.f;
+  for (int t = 0; t < tiles; ++t) {
+    const float2 v = *(const float2 *)(part + ((int64_t)row * tiles + t) * 2);
+    sm += v.x; sq += v.y;
+  }
+  const float inv = 1.0f / (float)n, mean = sm * inv;
+  float var = sq * inv - mean * mean;
+  if (var < 0.f) var = 0.f;
+  *(float2 *)(out + (int64_t)row * 2) = make_float2(mean, rsqrtf(var + eps));
+}
+
 int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
   const bool n128 = d->n % 128 == 0;
   const bool ok256 = d->n % 256 == 0, ok320 = d->n % 320 == 0 && !d->geglu;
@@ -496,8 +512,16 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
 
   // ---- output-row LayerNorm statistics live in the ping-pong epilogue (one tile = whole rows)
   if (a.ln_out) {
-    const int bm = makespan(d->m, d->n, 192, d->n) * 1.06 < makespan(d->m, d->n, 256, d->n) ? 192 : 256;
-    return launch_pp(a, bm, d->n, s);
+    const int bn = d->n <= 320 ? d->n : d->n / 2;
+    const int bm = makespan(d->m, d->n, 192, bn) * 1.06 < makespan(d->m, d->n, 256, bn) ? 192 : 256;
+    if (int rc = launch_pp(a, bm, bn, s)) return rc;
+    if (a.ln_part) {
+      SP_CLEAR_STALE_ERROR();
+      hipLaunchKernelGGL(ln_part_finalize_kernel, dim3((d->m + 255) / 256), dim3(256), 0, s, (const float *)a.ln_part, a.ln_out,
+                         d->m, d->n / bn, d->n, a.ln_out_eps);
+      SP_CHECK_LAUNCH("sp_gemm_f16(ln_out finalize)");
+    }
+    return SP_OK;
   }
 
   // ---- persistent-stream tiles (gemm_ps.hip): linear contractions with several tiles per CU, where launch gap,
@@ -632,9 +656,17 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   a.res1 = (const f16 *)d->res1; a.res2 = (const f16 *)d->res2; a.d = (f16 *)d->d;
   a.ln_stats = d->ln_stats; a.ln_colsum = d->ln_colsum;
   a.ln_out = d->ln_out; a.ln_out_eps = d->ln_out_eps;
-  if (d->ln_out)
-    SP_REQUIRE((d->n == 256 || d->n == 320) && !d->geglu && d->n_store == 0 && !d->euler_out && d->ln_out_eps > 0.f,
-               "sp_gemm_f16: ln_out needs whole rows per tile (n = 256 or 320, got %d), no geglu / n_store / Euler tail", d->n);
+  if (d->ln_out) {
+    SP_REQUIRE((d->n == 256 || d->n == 320 || d->n == 512 || d->n == 640) && !d->geglu && d->n_store == 0 && !d->euler_out &&
+                   d->ln_out_eps > 0.f,
+               "sp_gemm_f16: ln_out needs rows of one or two tiles (n = 256, 320, 512 or 640, got %d), no geglu / n_store / "
+               "Euler tail", d->n);
+    if (d->n > 320) {                          // two tiles per row: per-tile sums go through the caller's workspace
+      SP_REQUIRE(d->workspace && ((uintptr_t)d->workspace & 7) == 0 && d->workspace_bytes >= (size_t)d->m * 2 * 2 * sizeof(float),
+                 "sp_gemm_f16: ln_out with n = %d needs a workspace of m * 16 bytes (8-byte aligned)", d->n);
+      a.ln_part = (float *)d->workspace;
+    }
+  }
   if (d->euler_out) {
     SP_REQUIRE(d->euler_latent && d->n == 64 && d->n_store == 4 && !d->geglu && !d->res1 && !d->res2 && d->oscale == 1.0f,
                "sp_gemm_f16: the Euler tail belongs to conv_out (n = 64, n_store = 4, no residuals, oscale 1)");

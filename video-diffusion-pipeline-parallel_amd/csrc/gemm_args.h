@@ -27,6 +27,7 @@ struct GemmArgs {
   const float *ln_colsum;   // fp32 [n]: row sums of the gamma-scaled weight
   float *ln_out;            // fp32 [m][2]: (mean, rstd) of the stored output rows, or null (ping-pong kernels, n == BN)
   float ln_out_eps;
+  float *ln_part;           // rows spanning two tiles: fp32 [m][tiles_n][2] raw (sum, sum of squares) per tile, folded by ln_part_finalize
   f16 *d;
   const char *zero;
   int64_t lda, ldr1, ldr2, ldd, hw, bias2_rows, ldb2;

@@ -182,7 +182,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
     }
   }
   PP_TRACE(7);
-  // ---- LayerNorm statistics of the rows about to be stored (ln_out; host: one tile spans the whole row, n == BN): every
+  // ---- LayerNorm statistics of the rows about to be stored (ln_out; host: a row is one tile, or two with ln_part): every
   // thread leaves (sum, sum of squares) of its eight final fp16 values in LDS -- the staged tile is in registers by now
   // -- and one thread per row folds the row's chunks in a fixed order.  fp32 sums over 256 / 320 values.
   if constexpr (!GEGLU) {
@@ -203,10 +203,14 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
       if (tid < PBM && mbase + tid < p.m) {
         float sm = 0.f, sq = 0.f;
         for (int c = 0; c < cpr; ++c) { const float2 v = part[tid * cpr + c]; sm += v.x; sq += v.y; }
-        const float inv = 1.0f / (float)bno, mean = sm * inv;
-        float var = sq * inv - mean * mean;
-        if (var < 0.f) var = 0.f;
-        *(float2 *)(p.ln_out + (mbase + tid) * 2) = make_float2(mean, rsqrtf(var + p.ln_out_eps));
+        if (p.ln_part) {                       // the row continues in the next tile: raw sums, folded by ln_part_finalize
+          *(float2 *)(p.ln_part + ((mbase + tid) * p.tiles_n + tile_n) * 2) = make_float2(sm, sq);
+        } else {
+          const float inv = 1.0f / (float)bno, mean = sm * inv;
+          float var = sq * inv - mean * mean;
+          if (var < 0.f) var = 0.f;
+          *(float2 *)(p.ln_out + (mbase + tid) * 2) = make_float2(mean, rsqrtf(var + p.ln_out_eps));
+        }
       }
     }
   }

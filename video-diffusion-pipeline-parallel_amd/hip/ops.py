@@ -108,7 +108,8 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
         d.euler_ld_eps = int(euler.get("ld_eps", 0))
         d.euler_sigma, d.euler_sigma_next = float(euler["sigma"]), float(euler["sigma_next"])
         d.euler_frames, d.euler_hw = int(euler["frames"]), int(euler["hw"])
-    if workspace is not None and ln_out is None:   # fp32 scratch for split-K (few rows, long K); too small a buffer simply disables it
+    if workspace is not None:      # fp32 scratch: split-K (few rows, long K; too small a buffer simply disables it), or the
+        # per-tile row sums of a two-tile ln_out
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     if ln_out is not None:         # (mean, rstd) of the output rows, for the next contraction's folded LayerNorm
         if ln_out.dtype != torch.float32 or tuple(ln_out.shape) != (m, 2) or not ln_out.is_contiguous():

@@ -344,13 +344,16 @@ class SVDUNetHIP:
         out = kw.pop("out", None)
         # ``ln_next``: the contraction that will consume this output through a folded LayerNorm.  Where one tile spans a
         # whole output row (256 / 320 channels: level 0) the epilogue leaves that LayerNorm's (mean, rstd) beside the
-        # output and _ln_stats finds them there instead of reading the tensor again.
+        # output and _ln_stats finds them there instead of reading the tensor again (512 / 640 channels, level 1: two tiles
+        # per row, their sums meet in a 16-byte-per-row scratch).
         ln_next = kw.pop("ln_next", None)
         st = None
-        if ln_next is not None and layer.n_true in (256, 320) and layer.n == layer.n_true and not layer.geglu \
+        ws = r.sk_ws if m <= self.SPLITK_MAX_ROWS else None
+        if ln_next is not None and layer.n_true in (256, 320, 512, 640) and layer.n == layer.n_true and not layer.geglu \
                 and "euler" not in kw:
             st = torch.empty((m, 2), dtype=torch.float32, device=self.device)
             kw.update(ln_out=st, ln_out_eps=ln_next.ln_eps)
+            ws = torch.empty((m, 4), dtype=torch.float32, device=self.device) if layer.n_true > 320 else None
         if out is None:
             out = self._buf(m, layer.n_true)
         elif out.shape != (m, layer.n_true):
@@ -366,7 +369,7 @@ class SVDUNetHIP:
             raise RuntimeError("this contraction carries a folded LayerNorm: pass ln_stats")
         ops.gemm(a, layer.w, out, m=m, n=layer.n, cin=layer.cin, mode=layer.mode, conv=conv, temporal=temporal,
                  bias=layer.bias, geglu=layer.geglu, n_store=n_store, ldd=out.stride(0), lda=a.stride(0),
-                 ln_colsum=layer.colsum, workspace=r.sk_ws if m <= self.SPLITK_MAX_ROWS else None, **kw)
+                 ln_colsum=layer.colsum, workspace=ws, **kw)
         if st is not None:
             out._row_ln_stats = (st, ln_next.ln_eps)
         return out
