@@ -692,7 +692,7 @@ def main():
         # The line carries that commit and the algorithmic bytes (every operand / output / residual element once,
         # measured from this run's launches) so that the over-fetch ratio can be read off directly.
         traffic, traffic_src, traffic_commit = None, None, None
-        for name in ("r03m_pmc_traffic.json", "r03k_pmc_traffic.json", "r03i_pmc_traffic.json", "r03f_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r03n_pmc_traffic.json", "r03k_pmc_traffic.json", "r03i_pmc_traffic.json", "r03f_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pj.get("micro_batch", 1) != mb:      # bytes per launch scale with the videos per UNet call
