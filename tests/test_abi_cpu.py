@@ -60,3 +60,20 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         hip.load()
+
+
+def test_documented_binding_in_integration_md_matches_the_library():
+    """INTEGRATION.md is where a reference maintainer copies the ctypes stub from: its GemmDesc must be the library's
+    struct field for field (a shorter mirror makes sp_gemm_f16 read past the caller's struct), and it must carry the
+    load-time size check."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    start = text.index("class GemmDesc(ctypes.Structure)")
+    block = text[start:text.index("lib.sp_gemm_f16.argtypes", start)]
+    fields_src = block[block.index("_fields_ = ["):]
+    pairs = re.findall(r'\("([a-z0-9_]+)",\s*ctypes\.(c_[a-z0-9_]+)\)', fields_src)
+    assert pairs, "no fields parsed out of INTEGRATION.md"
+    mirror = [(name, getattr(ctypes, ctype)) for name, ctype in pairs]
+    assert mirror == list(hip.GemmDesc._fields_)
+    doc_struct = type("DocGemmDesc", (ctypes.Structure,), {"_fields_": mirror})
+    assert ctypes.sizeof(doc_struct) == hip.load().sp_gemm_desc_size()
+    assert "sp_gemm_desc_size()" in block and "raise" in block, "the documented stub must refuse a size mismatch"
