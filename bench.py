@@ -81,7 +81,7 @@ class Watchdog:
                 os._exit(3)
 
 
-def describe_rank(rank, n, device, ring, rotating, conc, selftest):
+def describe_rank(rank, n, device, ring, rotating, conc, selftest, transport=None, probe=None):
     """One stderr line per rank before the timed region: what a failed scaling run needs for its post-mortem."""
     backend = dist.get_backend() if n > 1 else "none"
     try:
@@ -89,10 +89,115 @@ def describe_rank(rank, n, device, ring, rotating, conc, selftest):
     except Exception as exc:  # noqa: BLE001
         rccl = f"unavailable ({exc!r})"
     sched = "single GPU" if n == 1 else ("ring" if ring else "chain" + (" + rotating extra step" if rotating else ""))
-    print(f"[rank {rank}/{n}] device {device} ({torch.cuda.get_device_name(device)}), torch {torch.__version__}, "
+    name = torch.cuda.get_device_name(device) if device.type == "cuda" else "host cores"
+    # torch's ProcessGroupNCCL gives every un-batched isend/irecv PAIR its own two-rank communicator and stream, keyed
+    # "low:high" (pointToPoint -> getKeySendRecv); grouped batch_isend_irecv uses the device-keyed world communicator
+    keys = {"from_rank-1": f"{rank - 1}:{rank}" if rank > 0 else None, "to_rank+1": f"{rank}:{rank + 1}" if rank < n - 1 else None}
+    print(f"[rank {rank}/{n}] device {device} ({name}), torch {torch.__version__}, "
           f"backend {backend}, RCCL {rccl}, schedule {sched}, {conc} videos in flight, ring self-test: {selftest}, "
+          f"transport {transport}, p2p communicator keys {keys}, p2p probe {probe}, "
           f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, "
           f"NCCL_MAX_P2P_NCHANNELS={os.environ.get('NCCL_MAX_P2P_NCHANNELS')}", file=sys.stderr, flush=True)
+
+
+def p2p_probe(rank, n, device, delay=0.4):
+    """Does a receive from rank-1 that is parked (its sender has not sent yet) hold up this rank's send to rank+1?
+    The chain posts the receive of video i+1 one UNet step BEFORE it sends video i (pipeline._SideStreamLink), which is
+    only harmless if torch keeps the two directions on separate communicators / streams (it keys un-batched P2P by the
+    rank pair; that is version behaviour, so it is MEASURED here once per run, N >= 3): rank 0 sends `delay` seconds
+    late; every middle rank posts its receive first and sends at once; a rank whose message arrives at about `delay`
+    instead of at about zero sat behind its upstream's parked receive.  Every rank returns the same dict; with
+    `serialised` the caller posts receives after sends (PipelineStage link.post_after_send).  ~delay seconds, untimed."""
+    if n < 3:
+        return {"ran": False, "why": "needs >= 3 ranks"}
+    cuda = device.type == "cuda"
+    out_t = torch.full((256,), float(rank), device=device)
+    in_t = torch.empty(256, device=device)
+    side = torch.cuda.Stream(device=device) if cuda else None
+    if cuda:
+        torch.cuda.synchronize(device)      # Gloo reads GPU tensors from the host, outside any stream order
+
+    def on_side():
+        return torch.cuda.stream(side) if cuda else _Null()
+
+    def round_trip(late):
+        """irecv(rank-1) posted first, then isend(rank+1) (rank 0 `late` seconds late); seconds until this rank's message
+        had landed.  work.wait() orders the side stream behind an RCCL transfer (it does not block the host), Gloo's blocks."""
+        dist.barrier()
+        t0 = time.perf_counter()
+        works = []
+        with on_side():
+            if rank > 0:
+                works.append(dist.irecv(in_t, src=rank - 1))
+            if rank == 0 and late:
+                time.sleep(late)
+            if rank < n - 1:
+                works.append(dist.isend(out_t, dst=rank + 1))
+            for w in works:
+                w.wait()
+        arrived = 0.0
+        if rank > 0:
+            if cuda:
+                side.synchronize()      # (a middle rank's send has completed by then as well: rank+1 posts at once)
+            arrived = time.perf_counter() - t0
+        if cuda:
+            torch.cuda.synchronize(device)
+        return arrived
+
+    round_trip(0.0)      # creates the pair communicators (lazy, blocking the host until both peers call) outside the timing
+    arrived = round_trip(delay)
+    ok = rank == 0 or float(in_t[0]) == float(rank - 1)
+    mine = {"rank": rank, "arrived_s": round(arrived, 4), "ok": bool(ok)}
+    allr = [None] * n
+    dist.all_gather_object(allr, mine)
+    # rank 1 must wait for the late sender; ranks >= 2 must NOT (their upstream sent at once unless it was held up)
+    held = [r["rank"] for r in allr if r["rank"] >= 2 and r["arrived_s"] > 0.5 * delay]
+    return {"ran": True, "delay_s": delay, "arrived_s": [r["arrived_s"] for r in allr], "data_ok": all(r["ok"] for r in allr),
+            "ranks_that_waited_behind_a_parked_receive": held, "serialised": bool(held)}
+
+
+class _Null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+class _HostEvent:
+    """torch.cuda.Event stand-in of --rehearse-cpu (CPU work is synchronous: record() is a timestamp)."""
+
+    def __init__(self, enable_timing=True):
+        self.t = None
+
+    def record(self, *_):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return 1e3 * (other.t - self.t)
+
+
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, cut by the cgroup CPU quota if there is one."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    cores = min(cores, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return cores
 
 
 def parse():
@@ -132,17 +237,24 @@ def parse():
                     help="skip the edge-stage timings (temporal-VAE decode, CLIP / VAE image encode; reported beside the "
                          "headline metric, never inside it)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="NOT a measurement: run this script's whole multi-rank path (launcher, process group, rotating "
+                         "chain / ring, watchdog, all_gather_object, steady-state arithmetic, JSON line) with the simulator's "
+                         "DummyUNet on CPU tensors over Gloo, so that `--gpus 8` can be rehearsed on a box without 8 GPUs")
     ap.add_argument("--seed", type=int, default=42)
     return ap.parse_args()
 
 
 def cpu_baseline(frames_full, h, w, total_steps):
-    """Oracle fp32 UNet (plain PyTorch CPU) on a bounded sample: one forward at 4 of 14 frames; scaled by the
-    algorithmic FLOP ratio to 14 frames x total_steps (about 10-20 s of host work)."""
+    """Oracle fp32 UNet (plain PyTorch CPU) timed on this host: ONE full forward at the benchmark's own shape with
+    min(usable cores, 64) threads (about 15-40 s of host work), x total_steps = seconds per video; nothing is
+    extrapolated.  On a host with fewer than 12 usable cores (the build container) the sample is 4 of the frames, scaled
+    by the algorithmic FLOP ratio, and the record says so."""
     from oracle.svd_unet_ref import SVDUNetConfig, SVDUNetRef, unet_flops
 
     cores = os.cpu_count() or 1
-    threads = min(cores, 16)
+    usable = usable_cores()
+    threads = max(1, min(usable, 64))
     torch.set_num_threads(threads)
     cfg = SVDUNetConfig.svd()
     with torch.device("meta"):
@@ -151,7 +263,8 @@ def cpu_baseline(frames_full, h, w, total_steps):
     with torch.no_grad():
         for p in ref.parameters():
             p.fill_(0.01)
-    sample_frames = 4
+    full = usable >= 12
+    sample_frames = frames_full if full else min(4, frames_full)
     x = torch.randn(1, sample_frames, 8, h, w)
     ctx = torch.randn(1, 1, cfg.cross_attention_dim)
     ids = torch.tensor([[5.0, 127.0, 0.02]])
@@ -162,10 +275,11 @@ def cpu_baseline(frames_full, h, w, total_steps):
     scale = unet_flops(cfg, frames_full, h, w)["total"] / unet_flops(cfg, sample_frames, h, w)["total"]
     videos_per_s = 1.0 / (dt * scale * total_steps)
     del ref
-    return {"value": videos_per_s, "unit": "videos/s", "cores": threads, "host_cores": cores, "kind": "port",
-            "extrapolated": True,
-            "sample": f"oracle fp32 UNet (torch CPU), 1 forward at {sample_frames} of {frames_full} frames "
-                      f"{h}x{w} in {dt:.1f}s, scaled by FLOP ratio {scale:.2f} x {total_steps} steps"}
+    return {"value": videos_per_s, "unit": "videos/s", "cores": threads, "host_cores": cores, "usable_cores": usable,
+            "kind": "port", "extrapolated": not full, "forward_s": dt,
+            "sample": f"oracle fp32 UNet (torch CPU, {threads} threads), 1 forward at {sample_frames} of {frames_full} frames "
+                      f"{h}x{w} in {dt:.1f}s" + ("" if full else f", scaled by FLOP ratio {scale:.2f}")
+                      + f", x {total_steps} steps per video"}
 
 
 def _sim_worker(rank, ws, init_file, out_file, c, hid, shape, steps, reps, threads):
@@ -227,7 +341,7 @@ def cpu_simulator():
     out = {"host_cores": cores, "rows": []}
     for ws, c, hid, shape, steps, reps in ((1, 8, 16, (1, 8, 8, 32, 32), 8, 5), (2, 8, 16, (1, 8, 8, 32, 32), 8, 5),
                                            (1, 4, 64, (1, 4, 14, 72, 128), 8, 2), (2, 4, 64, (1, 4, 14, 72, 128), 8, 2)):
-        threads = max(1, min(cores, 16) // ws)
+        threads = max(1, min(usable_cores(), 16) // ws)
         dt = _sim_time(ws, c, hid, shape, steps, reps, threads)
         out["rows"].append({"workload": f"DummyUNet({c},{hid}) {tuple(shape)} fp32, {steps} steps", "world_size": ws,
                             "backend": "gloo", "threads_per_rank": threads, "samples_per_s": 1.0 / dt,
@@ -254,6 +368,8 @@ def vae_decode_leg(device, frames, h, w):
     gen = torch.Generator(device=device).manual_seed(7)
     lat = (torch.randn((1, 4, frames, h, w), generator=gen, device=device) * cfg.scaling_factor).half()
     chunk = 14                                           # the reference's decode_chunk_size
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(device)           # peak of THIS leg, not of the process
     with torch.no_grad():
         dec.decode_latents(lat, frames, decode_chunk_size=chunk)
         torch.cuda.synchronize(device)
@@ -400,7 +516,7 @@ def launch_ranks(args, argv):
     n = args.gpus
     have = visible_gpus()
     shared = os.environ.get("VDPP_SHARE_GPU") == "1"
-    if have is not None and have < n and not shared:
+    if have is not None and have < n and not shared and not args.rehearse_cpu:
         print(f"bench.py: --gpus {n} but {have} GPU(s) are visible to this process (KFD topology / *_VISIBLE_DEVICES); "
               f"refusing to run a smaller job under the name of a larger one.  (Rehearsal on fewer cards: "
               f"VDPP_SHARE_GPU=1 PIPELINE_BACKEND=gloo.)", file=sys.stderr)
@@ -451,11 +567,14 @@ def main():
         # never report one job size under the name of another
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} "
                          f"(or plain `python bench.py --gpus {args.gpus}`, which starts its own ranks)")
+    rehearse = args.rehearse_cpu
+    if rehearse:
+        os.environ["PIPELINE_BACKEND"] = "gloo"
     rccl_env = p2p_env(os.environ) if world > 1 else {}
     _imports()
     shared = os.environ.get("VDPP_SHARE_GPU") == "1"
     have = torch.cuda.device_count()
-    if have < world and not shared:
+    if have < world and not shared and not rehearse:
         raise SystemExit(f"bench.py: --gpus {world} but torch sees {have} device(s); refusing to run (rehearsal on fewer "
                          f"cards: VDPP_SHARE_GPU=1 PIPELINE_BACKEND=gloo)")
     n = world
@@ -464,10 +583,11 @@ def main():
     steps = args.steps if args.steps is not None else (16 if n == 1 else 32 * n)
     # How many videos a GPU keeps in flight: `mb` videos travel together as ONE pipeline sample of shape (mb,4,F,H,W)
     # (north_star: "micro-batched pipeline"), `conc` samples are interleaved on separate HIP streams.  More in flight
-    # raises the rate of a busy stage (measured ms per video and UNet forward on one MI355X: 52.3 at 1 x 1, 49.4 at
-    # 1 x 2 streams, 49.8 at batch 2 x 1, 47.5 at 2 x 2) but lengthens the chain's fill and drain, which matters when
-    # the job is short for its N: pick the pair with the smallest predicted time (groups + N - 1) x group time.
-    # `steps` and `value` keep counting VIDEOS.
+    # raises the rate of a busy stage but lengthens the chain's fill and drain, which matters when the job is short for
+    # its N: pick the pair with the smallest predicted time (groups + N - 1) x group time.  The four per-forward times
+    # are a STATIC table (ms per video and UNet forward measured on one MI355X at 14 frames fp16 in round 3:
+    # tools/batch_vs_streams.py; their ORDER is what matters and holds at 25 frames too); the line says so
+    # (`in_flight_choice`).  `steps` and `value` keep counting VIDEOS.
     MS = {(1, 1): 52.3, (1, 2): 49.4, (2, 1): 49.8, (2, 2): 47.5}
     cands = [(b_, c_) for (b_, c_) in MS if steps % b_ == 0
              and (args.micro_batch is None or args.micro_batch == b_) and (args.concurrent is None or args.concurrent == c_)]
@@ -478,27 +598,38 @@ def main():
         conc = max(1, args.concurrent if args.concurrent is not None else 2)
     if mb < 1 or steps % mb:
         raise SystemExit(f"bench.py: --steps {steps} videos is not a whole number of micro-batches of {mb}")
+    warmup_requested = args.warmup
     warmup = args.warmup if args.warmup is not None else (2 * mb * conc if n == 1 else max(2 * n, 2 * mb * conc))
     n_samples = steps // mb
     warm_samples = -(-warmup // mb)
-    warmup = warm_samples * mb
+    warmup = warm_samples * mb              # whole micro-batches: --warmup 5 with micro-batches of two runs 6
 
     if shared:
         # rehearsal only (PIPELINE_BACKEND=gloo on a one-GPU box): ranks share the cards that exist; RCCL refuses this
         local_rank %= max(1, torch.cuda.device_count())
-    device = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(device)
+    device = torch.device("cpu") if rehearse else torch.device(f"cuda:{local_rank}")
+    cuda = device.type == "cuda"
+    if cuda:
+        torch.cuda.set_device(device)
+    else:
+        torch.set_num_threads(max(1, usable_cores() // n))
+    new_event = torch.cuda.Event if cuda else _HostEvent
+
+    def sync():
+        if cuda:
+            torch.cuda.synchronize(device)
+
     dog = Watchdog(args.watchdog if n > 1 else 0.0, rank)
     if n > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dog.beat("init_process_group")
-        init_distributed(backend=resolve_backend(None, simulator=False), rank=rank, world_size=n)
+        init_distributed(backend=resolve_backend(None, simulator=rehearse), rank=rank, world_size=n)
         dog.beat("first barrier")
         dist.barrier()      # create the world communicator collectively, before the first grouped send/recv needs it
         dog.beat("model construction")
     # what the process group itself saw (the JSON line reports THIS, not the --gpus argument)
-    me = {"rank": rank, "device": str(device), "name": torch.cuda.get_device_name(device),
-          "uuid": str(getattr(torch.cuda.get_device_properties(device), "uuid", ""))}
+    me = {"rank": rank, "device": str(device), "name": torch.cuda.get_device_name(device) if cuda else "host cores",
+          "uuid": str(getattr(torch.cuda.get_device_properties(device), "uuid", "")) if cuda else f"pid {os.getpid()}"}
     ranks_seen = [me]
     if n > 1:
         ranks_seen = [None] * n
@@ -513,14 +644,22 @@ def main():
     from vdpp_amd.models.svd_unet import StableVideoUNet
 
     T = args.total_steps
-    model = StableVideoUNet.from_random_init(StableVideoUNet._default_timestep_schedule(T), seed=0, device=device,
-                                             fp8_attention=args.fp8_attention, long_attention=args.long_attention or None)
-    torch.manual_seed(args.seed)  # same dummy conditioning on every rank
-    model.set_dummy_conditioning(mb, args.frames, args.height, args.width, device,
-                                 guidance_scale=args.guidance_scale)
+    lat_dtype = torch.float16
+    if rehearse:
+        from vdpp_amd.models import DummyUNet
+        torch.manual_seed(0)
+        model = DummyUNet(4, 16)                 # the simulator's model (ref src/models/dummy_unet.py), same weights on every rank
+        model.init_noise_sigma = 1.0
+        lat_dtype = torch.float32
+    else:
+        model = StableVideoUNet.from_random_init(StableVideoUNet._default_timestep_schedule(T), seed=0, device=device,
+                                                 fp8_attention=args.fp8_attention, long_attention=args.long_attention or None)
+        torch.manual_seed(args.seed)  # same dummy conditioning on every rank
+        model.set_dummy_conditioning(mb, args.frames, args.height, args.width, device,
+                                     guidance_scale=args.guidance_scale)
     passes = 2 if (args.guidance_scale or 0) > 1.0 else 1
     shape = torch.Size((mb, 4, args.frames, args.height, args.width))
-    spec = LatentSpec(shape=shape, dtype=torch.float16, device=device)
+    spec = LatentSpec(shape=shape, dtype=lat_dtype, device=device)
     import logging
     quiet = logging.getLogger("bench.quiet"); quiet.setLevel(logging.ERROR)
     ring = n > 1 and args.ring and not args.no_ring
@@ -537,7 +676,7 @@ def main():
                                             dist.P2POp(dist.irecv, probe_in, (rank - 1) % n)])
             for wk in works:
                 wk.wait()
-            torch.cuda.synchronize(device)
+            sync()
             if float(probe_in[0]) != float((rank - 1) % n):
                 ok.zero_()
         except Exception as exc:  # noqa: BLE001
@@ -551,7 +690,13 @@ def main():
                                                 latent_spec=spec, balanced=True, concurrent_samples=conc,
                                                 rotate=rotating, ring=ring),
                           logger=quiet)
-    describe_rank(rank, n, device, ring, rotating, conc, selftest)
+    probe = {"ran": False, "why": "single rank" if n == 1 else "ring schedule (grouped exchanges)"}
+    if n > 1 and not ring:
+        dog.beat("p2p probe")
+        probe = p2p_probe(rank, n, device)
+        if probe.get("serialised") and stage._link is not None:
+            stage._link.post_after_send = True
+    describe_rank(rank, n, device, ring, rotating, conc, selftest, stage.transport, probe)
     steps_done = [0]
     inner_model = model.forward
 
@@ -565,13 +710,13 @@ def main():
 
     def supplier(i):
         gen.manual_seed(args.seed + i)
-        return torch.randn(shape, generator=gen, device=device, dtype=torch.float16) * model.init_noise_sigma
+        return torch.randn(shape, generator=gen, device=device, dtype=lat_dtype) * model.init_noise_sigma
 
     def fence():
-        torch.cuda.synchronize(device)
+        sync()
         if n > 1:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        sync()
 
     with torch.no_grad():
         if warmup > 0:
@@ -580,15 +725,16 @@ def main():
             stage.drain()
         dog.beat("fence before the timed region")
         fence()
-        torch.cuda.reset_peak_memory_stats(device)      # ref src/modes/benchmark.py:240-249: peak of the timed region
+        if cuda:
+            torch.cuda.reset_peak_memory_stats(device)      # ref src/modes/benchmark.py:240-249: peak of the timed region
         done_events = []
 
         def on_done(_idx):   # runs on the finishing sample's stream, right after its last step was enqueued
-            ev = torch.cuda.Event(enable_timing=True); ev.record(); done_events.append(ev)
+            ev = new_event(enable_timing=True); ev.record(); done_events.append(ev)
 
         stage.sample_done_hook = on_done
         t0 = time.perf_counter()
-        start_ev = torch.cuda.Event(enable_timing=True); start_ev.record()
+        start_ev = new_event(enable_timing=True); start_ev.record()
         stage.run_many(n_samples, input_supplier=(lambda i: supplier(warm_samples + i)) if (rank == 0 or ring) else None)
         stage.drain()
         dog.beat("fence after the timed region")
@@ -596,11 +742,15 @@ def main():
         elapsed = time.perf_counter() - t0
     dog.beat("reduction of the timings")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    peaks = [torch.cuda.max_memory_allocated(device) / 2**30]
+    my_peak = torch.cuda.max_memory_allocated(device) / 2**30 if cuda else 0.0
+    peaks = [my_peak]
+    transports = [stage.transport]
     if n > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         peaks = [None] * n
-        dist.all_gather_object(peaks, torch.cuda.max_memory_allocated(device) / 2**30)
+        dist.all_gather_object(peaks, my_peak)
+        transports = [None] * n
+        dist.all_gather_object(transports, stage.transport)
     elapsed = float(tmax.item())
 
     # steady-state figure in the reference's definition (benchmark.py:254-267): successive completion
@@ -632,18 +782,29 @@ def main():
         flops_exec = forward_flops(UNetConfig.svd(), args.frames, args.height, args.width,
                                 count_cross_attn_qo=False)["total"]
         out = {
-            "metric": "steady-state videos/sec (whole node), SVD 14f x 25step",
+            "metric": ("REHEARSAL, NOT A MEASUREMENT (DummyUNet on CPU tensors over Gloo through the benchmark's multi-rank "
+                       "path): " if rehearse else "") + "steady-state videos/sec (whole node), SVD 14f x 25step",
             "value": value, "unit": "videos/s", "n_gpus": n, "steps": steps, "warmup": warmup,
+            "warmup_requested": warmup_requested,     # --warmup is rounded up to whole micro-batches
+            "in_flight_choice": {"micro_batch": mb, "streams": conc, "how": "static table of four per-forward times "
+                                 "measured in round 3 (tools/batch_vs_streams.py), smallest predicted job time"
+                                 if cands else "given on the command line", "table_ms_per_video_forward":
+                                 {f"{b_}x{c_}": v for (b_, c_), v in MS.items()}},
+            "transport_per_rank": transports, "p2p_probe": probe,
             "world_size_seen_by_process_group": dist.get_world_size() if n > 1 else 1,
             "backend": dist.get_backend() if n > 1 else "none", "ranks": ranks_seen, "rccl_env": rccl_env,
             "gpus_shared_between_ranks": bool(shared and n > 1), "micro_batch": mb, "streams_per_gpu": conc,
             "peak_memory_gb_per_rank": [round(m, 3) for m in peaks], "max_peak_memory_gb": round(max(peaks), 3),
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f16+fp8 attention" if args.fp8_attention else "f16", "data": "synthetic",
-            "config": {"workload": f"SVD img2vid UNet (1.52B params, random init), latent (1,4,{args.frames},"
-                                   f"{args.height},{args.width}) fp16, {T} steps, {passes} UNet pass/step "
+            "config": {"workload": ("DummyUNet(4,16) fp32 on CPU (rehearsal), " if rehearse else
+                                    "SVD img2vid UNet (1.52B params, random init), ") +
+                                   f"latent (1,4,{args.frames},{args.height},{args.width}) fp16 per video, every UNet call on "
+                                   f"({mb},4,{args.frames},{args.height},{args.width}) [= ({mb},{args.frames},8,{args.height},"
+                                   f"{args.width}) UNet sample], {T} steps, {passes} UNet pass/step "
                                    f"(guidance_scale={args.guidance_scale}), micro-batches of {mb} video(s) per UNet "
-                                   f"call, {conc} micro-batches in flight per GPU on separate HIP streams"
+                                   f"call (the reference benchmark's batch_size=1 is --micro-batch 1), {conc} micro-batches "
+                                   f"in flight per GPU on separate HIP streams"
                                    + (", spatial attention on fp8-e4m3 MFMA" if args.fp8_attention else "")
                                    + (", level-0 attention through attn_long_kernel" if args.long_attention else ""),
                        "stage_steps": stage_sizes(T, n, balanced=True),
@@ -668,6 +829,16 @@ def main():
                                         + ("" if n == 1 else " on the bottleneck stage (includes pipeline fill of the timed region)")}
 
     # ---- per-kernel roofline of the dominant kernel, measured live with events on the launch stream
+    if rehearse:
+        if rank == 0:
+            out["rehearsal"] = "cpu"
+            out.pop("step_roofline", None)
+            print(json.dumps(out), flush=True)
+        if n > 1:
+            dist.barrier()
+            finalize_distributed()
+        dog.stop()
+        return
     if rank == 0 and not args.no_roofline:
         with torch.no_grad():
             lat = supplier(0)

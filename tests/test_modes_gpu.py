@@ -94,13 +94,31 @@ def test_step_pipeline_of_the_real_model_is_bit_identical_across_world_sizes(tmp
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     outs = {}
-    for i, (world, schedule) in enumerate([(1, "rotate"), (2, "rotate"), (4, "rotate"), (2, "ring")]):
+    # (world, schedule, hand-off): "link" = pipeline._SideStreamLink between real processes (pre-posted irecv into fresh
+    # buffers, isend behind an event of the compute stream, take / drain) -- over Gloo its events are waited for on the
+    # host, the call sequence and the bookkeeping are the RCCL path's.  4 ranks + their launcher + this test process = the
+    # six processes that may have this box's one GPU open at a time.
+    for i, (world, schedule, link) in enumerate([(1, "rotate", False), (2, "rotate", True), (4, "rotate", True),
+                                                 (2, "ring", False)]):
         out = tmp_path / f"w{world}_{schedule}.pt"
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                "--master-addr", "127.0.0.1", "--master-port", str(29650 + i),
                os.path.join(root, "tools", "pp_equivalence.py"), "--out", str(out), "--schedule", schedule]
+        if link:
+            cmd.append("--async-link")
         res = subprocess.run(cmd, env=env, timeout=400, capture_output=True, text=True)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+        if link:
+            # every downstream rank received its three latents through the link, and all but the first of them had been
+            # posted ahead of time (one UNet step before the previous video's send)
+            seen = re.findall(r"\[rank (\d+)\] transport (\{.*\})", res.stdout)
+            assert len(seen) == world, res.stdout[-3000:]
+            for rk, txt in seen:
+                tr = eval(txt)
+                assert tr["kind"] == "side-stream link" and tr["host_ordered"] is True
+                assert tr["recv_taken"] == (3 if int(rk) > 0 else 0) and tr["sent"] == (3 if int(rk) < world - 1 else 0)
+                if int(rk) > 0:
+                    assert tr["recv_posted_ahead"] >= 2, tr
         outs[(world, schedule)] = torch.load(out)
     base = outs[(1, "rotate")]
     assert len(base) == 3 and all(torch.isfinite(t.float()).all() for t in base)

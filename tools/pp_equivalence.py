@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--concurrent", type=int, default=2)
     ap.add_argument("--frames", type=int, default=14)
     ap.add_argument("--steps", type=int, default=25)
+    ap.add_argument("--async-link", action="store_true",
+                    help="hand latents over through pipeline._SideStreamLink (pre-posted irecv, isend behind an event, fresh "
+                         "receive buffers) instead of blocking send/recv; over Gloo the link orders on the host")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     dev = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', rank)) % max(1, torch.cuda.device_count())}")
@@ -35,7 +38,7 @@ def main():
     spec = LatentSpec(shape=torch.Size((1, 4, args.frames, 72, 128)), dtype=torch.float16, device=dev)
     cfg = PipelineConfig(total_steps=args.steps, timesteps=list(range(args.steps)), world_size=world, rank=rank,
                          latent_spec=spec, balanced=True, rotate=args.schedule == "rotate", ring=args.schedule == "ring",
-                         concurrent_samples=args.concurrent)
+                         concurrent_samples=args.concurrent, async_comm=True if (args.async_link and world > 1) else None)
     stage = PipelineStage(model, cfg)
     if os.environ.get("PPEQ_DEBUG"):        # checksum of what enters every step (first video only: concurrent 1)
         inner = model.forward
@@ -61,6 +64,8 @@ def main():
         assert out is not None and len(out) == args.samples
         torch.save([t.cpu() for t in out], args.out)
         print(f"world {world} schedule {args.schedule}: {len(out)} latents -> {args.out}", flush=True)
+    stage.drain()
+    print(f"[rank {rank}] transport {stage.transport}", flush=True)
     finalize_distributed()
 
 

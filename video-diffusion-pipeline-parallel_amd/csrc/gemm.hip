@@ -21,6 +21,7 @@
 //   Out-of-image taps / rows past M read a zero page, so no branch sits in the main loop.
 //   The workgroup -> tile map is XCD-aware: the 8 XCDs each walk a contiguous run of tiles with N
 //   fastest, so an A tile is fetched from HBM once per XCD L2 and re-used by all N tiles.
+#include <cstring>
 #include "gemm_args.h"
 #include <stdlib.h>
 
@@ -520,6 +521,7 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
       hipLaunchKernelGGL(ln_part_finalize_kernel, dim3((d->m + 255) / 256), dim3(256), 0, s, (const float *)a.ln_part, a.ln_out,
                          d->m, d->n / bn, d->n, a.ln_out_eps);
       SP_CHECK_LAUNCH("sp_gemm_f16(ln_out finalize)");
+      spgemm::note_kernel_suffix(" + ln_part_finalize_kernel");
     }
     return SP_OK;
   }
@@ -616,6 +618,10 @@ void note_kernel(const char *fmt, ...) {
   vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
   va_end(ap);
 }
+void note_kernel_suffix(const char *suffix) {
+  const size_t have = strlen(g_last_kernel);
+  snprintf(g_last_kernel + have, sizeof(g_last_kernel) - have, "%s", suffix);
+}
 }  // namespace spgemm
 
 extern "C" const char *sp_gemm_last_kernel(void) { return spgemm::g_last_kernel; }
@@ -626,7 +632,10 @@ extern "C" size_t sp_gemm_workspace_bytes(const sp_gemm_desc *d) {
   int sk = splitk_slices(d, taps, false);
   const int forced = splitk_slices(d, taps, true);
   if (forced > sk) sk = forced;                             // (enough for a forced split in tests as well)
-  return (size_t)sk * d->m * d->n * sizeof(float);
+  size_t need = (size_t)sk * d->m * d->n * sizeof(float);
+  // ln_out over rows of two tiles (n = 512 / 640): the per-tile (sum, sum of squares) pairs meet here
+  const size_t ln_part = (d->ln_out && d->n > 320) ? (size_t)d->m * 2 * 2 * sizeof(float) : 0;
+  return need > ln_part ? need : ln_part;
 }
 
 extern "C" int sp_gemm_set_route(int route, int bm, int bn) {

@@ -55,6 +55,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // name of the kernel instantiation the calling thread launched last (sp_gemm_last_kernel: profile summaries)
 void note_kernel(const char *fmt, ...);
+void note_kernel_suffix(const char *suffix);   // appended to the name note_kernel left (a follow-up launch of the same call)
 
 // ping-pong large-tile kernels (gemm_pp.hip): bm in {128 (bn 256 only), 192, 256}, bn in {256, 320}
 int launch_pp(GemmArgs &a, int bm, int bn, hipStream_t s);

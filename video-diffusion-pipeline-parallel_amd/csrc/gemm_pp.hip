@@ -222,6 +222,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
     const int col = tile_n * bno + c * 8;
     if (idx >= NCH || m >= p.m || col >= nstore) continue;
     if (col + 8 <= nstore) {
+#ifdef SP_GEMM_EXPERIMENTS
+      if (p.dbg & 256) __builtin_nontemporal_store(o[it], (f16x8 *)(p.d + m * p.ldd + col));
+      else
+#endif
       *(f16x8 *)(p.d + m * p.ldd + col) = o[it];
     } else {   // ragged last chunk (n_store): the residuals were not prefetched for it
       for (int e = 0; e < nstore - col; ++e) {

@@ -436,12 +436,24 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
           q[j][o] = out;
         }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef SP_GEMM_EXPERIMENTS
+      if (p.dbg & 256) {                                  // non-temporal stores (aux = 2): A/B only
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int o = 0; o < TNO / 2; ++o)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, q[j][o]), d_rsrc,
+                                                   (int)(((mrow0 + j * 16) * p.ldd + col0 + o * 32) * 2), 0, 2);
+      } else
+#endif
+      {
 #pragma unroll
       for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int o = 0; o < TNO / 2; ++o)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, q[j][o]), d_rsrc,
                                                  (int)(((mrow0 + j * 16) * p.ldd + col0 + o * 32) * 2), 0, 0);
+      }
     }
     c_tm = n_tm; c_tn = n_tn;
     PS_MARK(ps_epi);

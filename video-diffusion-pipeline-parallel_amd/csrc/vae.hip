@@ -13,6 +13,10 @@
 
 namespace {
 
+// A score that overflowed fp16 on its way out of the contraction (+-inf) is read as +-65504: the row then has a finite
+// maximum and no inf - inf = NaN; a single saturated score gets (correctly) all of the row's mass.
+__device__ __forceinline__ float finite_f16(f16 h) { return __builtin_amdgcn_fmed3f((float)h, -65504.0f, 65504.0f); }
+
 template <int MAXV>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(f16 *__restrict__ x, int64_t ld, int cols) {
   __shared__ float red[8];
@@ -27,7 +31,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(f16 *__restrict__ x, 
     if (o < oc) {
       v[i] = *(const f16x8 *)(row + o * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[i][e]);
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, finite_f16(v[i][e]));
     }
   }
   mx = wave_max(mx);
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(f16 *__restrict__ x, 
     const int o = tid + i * 256;
     if (o < oc) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += __builtin_amdgcn_exp2f(fmaf((float)v[i][e], 1.4426950408889634f, nm));
+      for (int e = 0; e < 8; ++e) s += __builtin_amdgcn_exp2f(fmaf(finite_f16(v[i][e]), 1.4426950408889634f, nm));
     }
   }
   s = wave_sum(s);
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(f16 *__restrict__ x, 
     if (o < oc) {
       f16x8 w;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) w[e] = (f16)(__builtin_amdgcn_exp2f(fmaf((float)v[i][e], 1.4426950408889634f, nm)) * inv);
+      for (int e = 0; e < 8; ++e) w[e] = (f16)(__builtin_amdgcn_exp2f(fmaf(finite_f16(v[i][e]), 1.4426950408889634f, nm)) * inv);
       *(f16x8 *)(row + o * 8) = w;
     }
   }

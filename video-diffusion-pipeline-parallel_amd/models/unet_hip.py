@@ -40,6 +40,14 @@ from . import weights as W
 from .unet_spec import UNetConfig, up_block_plan
 
 
+def _version(t):
+    """In-place-write counter of a tensor (inference tensors keep none: -1)."""
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
 def _f32(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
@@ -371,13 +379,16 @@ class SVDUNetHIP:
                  bias=layer.bias, geglu=layer.geglu, n_store=n_store, ldd=out.stride(0), lda=a.stride(0),
                  ln_colsum=layer.colsum, workspace=ws, **kw)
         if st is not None:
-            out._row_ln_stats = (st, ln_next.ln_eps)
+            # valid for exactly this tensor object in exactly this state (checked in _ln_stats): a view, a slice or an
+            # in-place write after the contraction silently falls back to the statistics pass
+            out._row_ln_stats = (st, ln_next.ln_eps, out.data_ptr(), _version(out), tuple(out.shape))
         return out
 
     def _ln_stats(self, layer: _Dense, x, **kw):
         """(mean, rstd) per row of x for the LayerNorm folded into ``layer``."""
         have = getattr(x, "_row_ln_stats", None)
-        if have is not None and not kw and have[1] == layer.ln_eps:
+        if (have is not None and not kw and have[1] == layer.ln_eps and have[2] == x.data_ptr() and have[3] == _version(x)
+                and have[4] == tuple(x.shape)):
             return have[0]                                # left there by the contraction that produced x
         st = torch.empty((x.shape[0], 2), dtype=torch.float32, device=self.device)
         ops.ln_stats(x, st, rows=x.shape[0], c=x.shape[1], eps=layer.ln_eps, **kw)

@@ -354,12 +354,16 @@ class TemporalDecoderHIP(_VAEKernels):
                            frames_per_item=num_frames, batch=bf // num_frames, frames=num_frames, h=h, w=w, scale=1.0)
         return out
 
-    def decode_latents(self, latents, num_frames: int, decode_chunk_size: int = 14):
+    def decode_latents(self, latents, num_frames: int, decode_chunk_size: int = 14, *, check_finite: bool = False):
         """``/root/reference/scripts/generate_video_demo.py:154-195``: latents (B, 4, F, H, W) fp16 -> frames
         (B, 3, F, 8H, 8W) fp32.  Division by ``scaling_factor`` first; the flattened (B, F) list is decoded
         ``decode_chunk_size`` entries per decoder call, each call ONE batch item of that many frames (the temporal
         layers see one chunk at a time), exactly as the reference does -- including chunks that straddle two videos
-        when the chunk size does not divide F."""
+        when the chunk size does not divide F.
+        ``check_finite``: this engine stores activations in fp16 where the reference upcasts the VAE to fp32
+        (``force_upcast``, ref :171-175, because activations of the TRAINED decoder can leave fp16's range); with the flag
+        the frames are checked (one device synchronisation) and a non-finite value raises ``FloatingPointError`` naming
+        the first bad frame instead of being returned as a picture."""
         if latents.dim() != 5 or latents.shape[1] != self.cfg.latent_channels or latents.shape[2] != num_frames:
             raise ValueError(f"decode_latents expects (B, {self.cfg.latent_channels}, F, H, W) with F = num_frames; "
                              f"got {tuple(latents.shape)}")
@@ -374,6 +378,12 @@ class TemporalDecoderHIP(_VAEKernels):
             n = min(decode_chunk_size, b * f - i)
             self._decode_chunk(latents, (c * f * hw, f * hw, hw), out, (3 * f * ohw, f * ohw, ohw), flat0=i, n=n,
                                frames_per_item=f, batch=1, frames=n, h=h, w=w, scale=1.0 / self.cfg.scaling_factor)
+        if check_finite:
+            bad = (~torch.isfinite(out)).flatten(3).any(-1).any(1)                       # (B, F)
+            if bool(bad.any()):
+                bi, fi = [int(v) for v in bad.nonzero()[0]]
+                raise FloatingPointError(f"decode_latents: non-finite values in video {bi}, frame {fi}: an activation left "
+                                         f"fp16's range (the reference runs this VAE in fp32, force_upcast)")
         return out
 
 

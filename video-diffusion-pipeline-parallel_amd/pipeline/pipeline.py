@@ -125,6 +125,16 @@ class _SideStreamLink:
         self.stream = torch.cuda.Stream(device=spec.device)
         self._pending: Deque[tuple] = deque()      # (work, buffer) of pre-posted irecvs, in message order
         self._in_flight: Deque[tuple] = deque()
+        # Gloo reads and writes a GPU tensor from host threads with no regard for HIP streams (see
+        # _gloo_moves_gpu_tensor): in that rehearsal mode (PIPELINE_BACKEND=gloo VDPP_ASYNC_COMM=1, ranks sharing a card)
+        # the events that RCCL would wait for on the side stream are waited for on the host instead.  Same call sequence,
+        # same buffers, same bookkeeping between two real processes; only the overlap is lost.
+        self.host_ordered = dist.is_initialized() and dist.get_backend() == "gloo"
+        # True: the receive of the next sample is posted right AFTER this sample's send instead of at the start of its
+        # last local step (bench.py sets it when its start-up probe finds that a parked receive from rank-1 holds up a
+        # send to rank+1, i.e. when both directions share one internal RCCL stream)
+        self.post_after_send = False
+        self.stats = {"recv_posted": 0, "recv_taken": 0, "sent": 0, "recv_posted_ahead": 0}
 
     # -- receive -------------------------------------------------------------------------
     def post_recv(self) -> None:
@@ -136,14 +146,20 @@ class _SideStreamLink:
         allocated.record(torch.cuda.current_stream(self.spec.device))
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(allocated)      # the allocator may hand back memory still in use on this stream
+            if self.host_ordered:
+                allocated.synchronize()
             work = dist.irecv(buf, src=self.rank - 1, tag=self.tag)
         self._pending.append((work, buf))
+        self.stats["recv_posted"] += 1
 
     def take(self) -> torch.Tensor:
         """Return the next latent; the *current compute stream* is made to wait for it, not the host."""
 
         if not self._pending:
             self.post_recv()
+        else:
+            self.stats["recv_posted_ahead"] += 1
+        self.stats["recv_taken"] += 1
         work, buf = self._pending.popleft()
         with torch.cuda.stream(self.stream):
             work.wait()  # stream-level dependency on the RCCL recv
@@ -165,8 +181,11 @@ class _SideStreamLink:
         latent.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
+            if self.host_ordered:
+                ready.synchronize()
             work = dist.isend(latent, dst=self.rank + 1, tag=self.tag)
         self._in_flight.append((work, latent))
+        self.stats["sent"] += 1
         while self._in_flight and self._in_flight[0][0].is_completed():
             self._in_flight.popleft()
 
@@ -196,16 +215,15 @@ class PipelineStage:
             rank=config.rank,
         )
         use_async = config.async_comm
-        if use_async is None and os.environ.get("VDPP_ASYNC_COMM", "1") == "0":
+        forced = os.environ.get("VDPP_ASYNC_COMM")
+        if use_async is None and forced == "0":
             use_async = False  # escape hatch: reference-style blocking send/recv on the compute stream
+        can_link = (config.latent_spec.device.type == "cuda" and config.world_size > 1 and dist.is_available()
+                    and dist.is_initialized())
         if use_async is None:
-            use_async = (
-                config.latent_spec.device.type == "cuda"
-                and config.world_size > 1
-                and dist.is_available()
-                and dist.is_initialized()
-                and dist.get_backend() == "nccl"
-            )
+            # RCCL by default; VDPP_ASYNC_COMM=1 also over Gloo with GPU latents (rehearsal of the link between real
+            # processes on a box whose ranks share a card: _SideStreamLink.host_ordered)
+            use_async = can_link and (dist.get_backend() == "nccl" or forced == "1")
         self._link: _SideStreamLink | None = (
             _SideStreamLink(config.latent_spec, config.rank, config.send_tag) if use_async else None
         )
@@ -258,7 +276,7 @@ class PipelineStage:
         verbose = self.logger.isEnabledFor(logging.INFO)
         for pos, step in enumerate(owned):
             if (pos == len(owned) - 1 and self._link is not None and self.config.rank > 0
-                    and self._more_samples_expected and self._link.posted == 0):
+                    and self._more_samples_expected and self._link.posted == 0 and not self._link.post_after_send):
                 self._link.post_recv()      # next sample's receive: resident no earlier than this last step
             began = time.time()
             latent = self.model(latent, step)  # the timestep VALUE is the argument (ref :95)
@@ -338,7 +356,7 @@ class PipelineStage:
             owned = [self._owned_timesteps(idx) for idx in group]
             rounds = max(len(o) for o in owned)
             for k in range(rounds):
-                if k == rounds - 1 and not first and self._link is not None:
+                if k == rounds - 1 and not first and self._link is not None and not self._link.post_after_send:
                     with torch.cuda.stream(self._streams[0]):   # ordered behind lane 0's second-to-last step
                         for _ in range(following):
                             self._link.post_recv()
@@ -357,6 +375,10 @@ class PipelineStage:
                 if last:
                     latents[j].record_stream(main)
                     main.wait_stream(self._streams[j])
+            if not first and self._link is not None and self._link.post_after_send:
+                with torch.cuda.stream(self._streams[0]):
+                    for _ in range(following):
+                        self._link.post_recv()
             self._log(f"samples {group[0]}..{group[-1]} issued on {len(group)} streams")
         return finished or None
 
@@ -519,6 +541,9 @@ class PipelineStage:
             return latent
 
         self._send_latent(latent)
+        if (self._link is not None and self._link.post_after_send and cfg.rank > 0 and self._more_samples_expected
+                and self._link.posted == 0):
+            self._link.post_recv()
         return None
 
     def drain(self) -> None:
@@ -526,6 +551,15 @@ class PipelineStage:
 
         if self._link is not None:
             self._link.drain()
+
+    @property
+    def transport(self) -> dict:
+        """What moves this stage's latents (bench.py prints it per rank): the side-stream link with its counters, or
+        the reference's blocking send/recv."""
+        if self._link is None:
+            return {"kind": "blocking send/recv on the compute stream"}
+        return dict(self._link.stats, kind="side-stream link", host_ordered=self._link.host_ordered,
+                    post_after_send=self._link.post_after_send)
 
 
 def _make_stage(model, *, total_steps, timesteps, world_size, rank, latent_spec, logger,
