@@ -228,8 +228,10 @@ def parse():
     ap.add_argument("--no-ring", action="store_true", help="(default now; kept for older command lines)")
     ap.add_argument("--watchdog", type=float, default=120.0,
                     help="seconds without progress after which a rank prints where it is and exits with status 3")
-    ap.add_argument("--long-attention", action="store_true",
-                    help="level-0 spatial attention through the frozen-reference kernel (csrc/attention_long.hip); off by default")
+    ap.add_argument("--long-attention", action="store_true", help="(default since round 4; kept for older command lines)")
+    ap.add_argument("--no-long-attention", action="store_true",
+                    help="level-0 spatial attention through the ordinary kernel instead of the frozen-reference kernel "
+                         "(csrc/attention_long.hip; its worst case is bounded at ~1.1-1.25x the ordinary kernel)")
     ap.add_argument("--fp8-attention", action="store_true",
                     help="spatial self-attention on fp8-e4m3 MFMA (BASELINE config 5; use with --frames 25 --total-steps 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -237,6 +239,11 @@ def parse():
                     help="skip the edge-stage timings (temporal-VAE decode, CLIP / VAE image encode; reported beside the "
                          "headline metric, never inside it)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--emit-frames", action="store_true",
+                    help="also time the pipeline WITH its last edge stage (secondary figure `frames_out`, never `value`): every "
+                         "finished latent is decoded to frames by the temporal VAE on a stream of its own beside the UNet "
+                         "steps, pipeline sample i on rank i mod N (models/edge_stages.py::FrameEmitter; ref "
+                         "scripts/generate_video_demo.py:418).  Default at N = 1 unless --no-decode; opt-in at N > 1")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="NOT a measurement: run this script's whole multi-rank path (launcher, process group, rotating "
                          "chain / ring, watchdog, all_gather_object, steady-state arithmetic, JSON line) with the simulator's "
@@ -393,6 +400,59 @@ def vae_decode_leg(device, frames, h, w):
     del dec, vid
     torch.cuda.empty_cache()
     return res
+
+
+def frames_out_leg(args, stage, supplier, device, n, rank, ring, mb, conc, fence, dog):
+    """The same pipeline with its last edge stage attached (secondary figure, never `value`): every finished pipeline
+    sample is decoded to frames (B,3,F,8H,8W) fp32 by the temporal VAE (random weights of the SVD architecture) on a HIP
+    stream of its own beside the UNet steps, sample i on rank i mod N -- the last rank forwards the 1-2 MB latent -- so that
+    no stage carries a whole decode per video (ref scripts/generate_video_demo.py:418 decodes on the last rank, after the
+    loop).  Barrier-bracketed like the headline figure; the last decode's completion is inside the timed region."""
+    from vdpp_amd.models.edge_stages import FrameEmitter
+    from vdpp_amd.models.vae_hip import TemporalDecoderHIP, VAEDecoderConfig, random_state_dict
+
+    cfg = VAEDecoderConfig.svd()
+    dec = TemporalDecoderHIP(cfg, random_state_dict(cfg, seed=0), device)
+    emitter = FrameEmitter(dec, stage, args.frames, decode_chunk_size=14, spread=True, keep="last")
+    hook = stage.sample_done_hook
+    stage.sample_done_hook = None
+    per = mb * conc
+    videos = max(2 * per, 8 if n == 1 else 8 * n)
+    videos = -(-videos // per) * per
+    samples = videos // mb
+    with torch.no_grad():
+        stage.run_many(max(1, (n if n > 1 else 1) * conc), input_supplier=supplier if (rank == 0 or ring) else None)   # warm-up
+        stage.drain()
+        emitter.finish(max(1, (n if n > 1 else 1) * conc))
+        emitter.reset()
+        fence()
+        t0 = time.perf_counter()
+        stage.run_many(samples, input_supplier=(lambda i: supplier(1000 + i)) if (rank == 0 or ring) else None)
+        stage.drain()
+        emitter.finish(samples)
+        fence()
+        dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    decoded = [emitter.stats["decoded"]]
+    if n > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        decoded = [None] * n
+        dist.all_gather_object(decoded, emitter.stats["decoded"])
+    dt = float(t.item())
+    shape = None
+    for fr in emitter.frames.values():
+        shape = list(fr.shape)
+    stage.finished_latent_hook = stage.after_sample_hook = None
+    stage.sample_done_hook = hook
+    del emitter, dec
+    torch.cuda.empty_cache()
+    return {"videos_per_s": videos / dt, "ms_per_video": 1e3 * dt / videos, "videos": videos,
+            "decodes_per_rank_incl_warmup": decoded, "frames_per_sample": shape, "output_dtype": "fp32",
+            "where": "pipeline sample i is decoded on rank i mod N, on a HIP stream of its own beside the UNet steps"
+                     if n > 1 else "on a HIP stream of its own beside the UNet steps of the following videos",
+            "note": "temporal VAE decoder with random weights of the SVD architecture; NOT `value`: the reference benchmark's "
+                    "videos end as latents (ref src/modes/benchmark.py), its demo decodes them on the last rank "
+                    "(ref scripts/generate_video_demo.py:418)"}
 
 
 def image_encode_leg(device, frames, h, w):
@@ -653,7 +713,7 @@ def main():
         lat_dtype = torch.float32
     else:
         model = StableVideoUNet.from_random_init(StableVideoUNet._default_timestep_schedule(T), seed=0, device=device,
-                                                 fp8_attention=args.fp8_attention, long_attention=args.long_attention or None)
+                                                 fp8_attention=args.fp8_attention, long_attention=False if args.no_long_attention else None)
         torch.manual_seed(args.seed)  # same dummy conditioning on every rank
         model.set_dummy_conditioning(mb, args.frames, args.height, args.width, device,
                                      guidance_scale=args.guidance_scale)
@@ -740,6 +800,10 @@ def main():
         dog.beat("fence after the timed region")
         fence()
         elapsed = time.perf_counter() - t0
+    frames_out = None
+    if not rehearse and not args.no_decode and (args.emit_frames or n == 1):
+        dog.beat("frames-out leg")
+        frames_out = frames_out_leg(args, stage, supplier, device, n, rank, ring, mb, conc, fence, dog)
     dog.beat("reduction of the timings")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     my_peak = torch.cuda.max_memory_allocated(device) / 2**30 if cuda else 0.0
@@ -806,7 +870,8 @@ def main():
                                    f"call (the reference benchmark's batch_size=1 is --micro-batch 1), {conc} micro-batches "
                                    f"in flight per GPU on separate HIP streams"
                                    + (", spatial attention on fp8-e4m3 MFMA" if args.fp8_attention else "")
-                                   + (", level-0 attention through attn_long_kernel" if args.long_attention else ""),
+                                   + (", level-0 attention through attn_spatial_kernel" if args.no_long_attention else
+                                      ", level-0 attention (rows >= 8,192 tokens) through attn_long_kernel"),
                        "stage_steps": stage_sizes(T, n, balanced=True),
                        "stage_steps_rotate_with_video_index": bool(rotating),
                        "schedule": ("ring: video i starts on rank i mod N and visits every rank once" if ring else
@@ -822,6 +887,10 @@ def main():
         bottleneck_steps = T / n if (rotating or ring) else max(stage_sizes(T, n, balanced=True))
         ms_forward = 1e3 * per_video / (bottleneck_steps * passes)
         out["ms_per_unet_forward" if n == 1 else "ms_per_unet_forward_bottleneck_stage"] = ms_forward
+        if frames_out is not None:
+            frames_out["latents_out_videos_per_s"] = value
+            frames_out["frames_out_over_latents_out"] = frames_out["videos_per_s"] / value
+            out["frames_out"] = frames_out
         out["step_roofline"] = {"bound": "mfma", "achieved": flops_exec / 1e12 / (ms_forward / 1e3),
                                 "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": flops_exec / 1e12 / (ms_forward / 1e3) / PEAK_FP16_TFLOPS,

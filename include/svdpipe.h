@@ -106,6 +106,12 @@ typedef struct sp_gemm_desc {
      n_store, no Euler tail; the call runs on the ping-pong kernels (no split-K).  Sums are folded in a fixed order:
      bit-reproducible.  NULL = off. */
   float *ln_out; float ln_out_eps;
+  /* Per-row-group weights (SP_A_LINEAR only): with w_group_rows > 0, output rows [g*w_group_rows, (g+1)*w_group_rows)
+     are multiplied with the weight matrix at w + g*w_group_stride halves instead of w (what a GroupNorm folded into the
+     linear layer behind it needs: one scaled copy of the weights per frame, sp_groupnorm_fold_linear_f16; combine with a
+     bias2 row per group).  w_group_rows must be a multiple of 128 (no tile may straddle two groups); the call runs on the
+     ping-pong kernels (no split-K).  0 = one weight matrix for every row. */
+  int64_t w_group_rows; int64_t w_group_stride;
 } sp_gemm_desc;
 
 int sp_gemm_f16(const sp_gemm_desc *desc, void *stream);
@@ -161,6 +167,21 @@ int sp_groupnorm_f16(const void *x, const float *gamma, const float *beta, void 
 int sp_groupnorm_ld_f16(const void *x, int64_t ldx, const float *gamma, const float *beta, void *y, int instances,
                         int64_t rows, int c, int groups, float eps, int fuse_silu, void *ws,
                         size_t ws_bytes, void *stream);
+
+/* GroupNorm (no activation) folded into the nn.Linear that consumes it -- diffusers TransformerSpatioTemporalModel:
+ * hidden = proj_in(norm(x)) -- so that the normalised tensor is never written or read:
+ *   GN(x)[r][c] = (x[r][c] - mean[i][g(c)]) * rstd[i][g(c)] * gamma[c] + beta[c]      (i = instance of row r)
+ *   proj_in(GN(x))[r][n] = sum_c x[r][c] * w_out[i][n][c] + bias_out[i][n]
+ *   w_out[i][n][c]  = fp16( w[n][c] * gamma[c] * rstd[i][g(c)] )
+ *   bias_out[i][n]  = bias[n] + sum_c beta[c]*w[n][c] - sum_c mean[i][g(c)] * float(w_out[i][n][c])
+ * (the mean term uses the ROUNDED weights, so it cancels exactly what the MFMA adds for a constant offset of the group).
+ * One statistics pass over x (the same kernels as sp_groupnorm_f16's first pass) + one small kernel that writes the
+ * instances * n * c scaled weights; the caller then runs sp_gemm_f16 on the RAW x with w = w_out, w_group_rows = rows,
+ * w_group_stride = n*c, bias = NULL, bias2 = bias_out, bias2_rows = rows.  x: fp16 [instances*rows][ldx] (C channels at
+ * the head of each row); w: fp16 [n][c]; gamma, beta, bias: fp32 (bias may be NULL); ws as for sp_groupnorm_f16. */
+int sp_groupnorm_fold_linear_f16(const void *x, int64_t ldx, const float *gamma, const float *beta, int instances,
+                                 int64_t rows, int c, int groups, float eps, const void *w, const float *bias, int n,
+                                 void *w_out, float *bias_out, void *ws, size_t ws_bytes, void *stream);
 
 /* LayerNorm over the last dim (torch.nn.LayerNorm in BasicTransformerBlock /
  * TemporalBasicTransformerBlock).  Optional pre-add of a per-frame vector

@@ -309,6 +309,70 @@ def test_groupnorm_large_mean_small_variance(inst, rows, c):
     check(y, ref)
 
 
+@pytest.mark.parametrize("inst,rows,c,n,off,pad,res", [(3, 256, 320, 320, 0.0, 0, False), (2, 512, 640, 640, 0.0, 0, True),
+                                                        (4, 256, 320, 320, 50.0, 320, True), (2, 384, 1280, 256, 5.0, 0, False),
+                                                        (28, 2304, 640, 640, 50.0, 0, True), (5, 1152, 64, 320, 50.0, 64, False)])
+def test_groupnorm_folded_into_the_linear_layer_behind_it(inst, rows, c, n, off, pad, res):
+    """proj_in(GroupNorm(x)) of a spatio-temporal transformer without the normalised tensor: sp_groupnorm_fold_linear_f16
+    (one statistics pass + per-instance scaled weights, the mean term taken from the ROUNDED weights) followed by
+    sp_gemm_f16 on the RAW x with w_group_rows / w_group_stride and one bias2 row per instance, against
+    F.linear(F.group_norm(x)) in fp64 on the fp16-rounded inputs.  Groups 50 standard deviations off zero (the offset must
+    cancel, not be rounded away), x as a column slice of a wider tensor (the skip half of a concatenation buffer), a
+    residual, the output-row LayerNorm statistics (ln_out) on top, 192-row tiles (rows = 384 / 1152)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(inst + rows + c + n)
+    cpg = c // 32
+    group_off = (torch.randint(0, 3, (32,), generator=g).float() - 1.0) * off
+    chan_off = group_off.repeat_interleave(cpg) + 0.3 * torch.randn(c, generator=g)
+    x = h(torch.randn(inst, rows, c, generator=g) * (0.5 + torch.rand(inst, 1, 1, generator=g)) + chan_off)
+    gamma, beta = 1.0 + 0.3 * torch.randn(c, generator=g), torch.randn(c, generator=g)
+    w = h(torch.randn(n, c, generator=g) / math.sqrt(c))
+    bias = torch.randn(n, generator=g)
+    r1 = h(torch.randn(inst * rows, n, generator=g)) if res else None
+    ref = F.group_norm(x.double().permute(0, 2, 1), 32, gamma.double(), beta.double(), eps=1e-6).permute(0, 2, 1)
+    ref = (ref.reshape(inst * rows, c) @ w.double().t() + bias.double())
+    if res:
+        ref = ref + 0.5 * r1.double()
+    ref = ref.float()
+    xd = torch.zeros(inst * rows, c + pad, dtype=torch.float16, device=DEV)
+    xd[:, :c] = x.reshape(inst * rows, c).half().to(DEV)
+    xv = xd[:, :c]
+    ws = torch.empty(ops.groupnorm_ws_bytes(inst, rows, c, 32), dtype=torch.uint8, device=DEV)
+    w_f = torch.empty(inst, n, c, dtype=torch.float16, device=DEV)
+    b_f = torch.empty(inst, n, dtype=torch.float32, device=DEV)
+    ops.groupnorm_fold_linear(xv, gamma.to(DEV), beta.to(DEV), w.half().to(DEV), bias.to(DEV), w_f, b_f, instances=inst,
+                              rows=rows, c=c, groups=32, eps=1e-6, n=n, ws=ws, ldx=c + pad)
+    out = torch.empty(inst * rows, n, dtype=torch.float16, device=DEV)
+    kw = dict(m=inst * rows, n=n, cin=c, lda=c + pad, bias2=b_f, bias2_rows=rows, w_group_rows=rows, w_group_stride=n * c)
+    if res:
+        kw.update(res1=r1.half().to(DEV), r1scale=0.5)
+    ops.gemm(xv, w_f, out, **kw)
+    # offsets of 50 sigma: |x| ~ 50 while the normalised values are ~1; the fp16 rounding of the scaled weights then shows
+    # as (offset/sigma) * 2^-11 of the signal, which the rounded-weights bias removes -- same tolerance as everywhere
+    check(out, ref, l2=3e-3, mx=2e-2)
+    if n in (320, 640, 256):                    # and the next LayerNorm's statistics from the same call
+        st = torch.empty(inst * rows, 2, dtype=torch.float32, device=DEV)
+        out2 = torch.empty_like(out)
+        wsl = torch.empty(inst * rows * 4, dtype=torch.float32, device=DEV) if n > 320 else None
+        ops.gemm(xv, w_f, out2, ln_out=st, ln_out_eps=1e-5, workspace=wsl, **kw)
+        assert torch.equal(out2, out)
+        o32 = out.float()
+        mean, var = o32.mean(-1), o32.var(-1, unbiased=False)
+        assert float((st[:, 0] - mean).abs().max()) <= 2e-3 * float(o32.abs().max())
+        assert float((st[:, 1] * torch.sqrt(var + 1e-5) - 1).abs().max()) <= 2e-3
+
+
+def test_gemm_rejects_row_groups_that_tiles_would_straddle():
+    ops = _ops()
+    a = torch.zeros(640, 320, dtype=torch.float16, device=DEV)
+    w = torch.zeros(2, 320, 320, dtype=torch.float16, device=DEV)
+    out = torch.empty(640, 320, dtype=torch.float16, device=DEV)
+    with pytest.raises(ops.HipKernelError, match="w_group_rows"):
+        ops.gemm(a, w, out, m=640, n=320, cin=320, w_group_rows=320, w_group_stride=320 * 320)      # not a multiple of 128
+    with pytest.raises(ops.HipKernelError, match="per-row-group"):
+        ops.gemm(a, w, out[:, :160], m=640, n=320, cin=320, geglu=True, w_group_rows=256, w_group_stride=320 * 320, ldd=320)
+
+
 @pytest.mark.parametrize("m,cin,n,extras,offset", [(1000, 320, 320, "", 0.0), (129024, 320, 320, "r", 2.0), (2016, 1280, 320, "r2", 0.0),
                                                     (5000, 640, 256, "b2", 20.0), (777, 64, 320, "r", 20.0), (64512, 1280, 256, "", 0.0),
                                                     # rows of two tiles: per-tile sums through a workspace + finalize kernel
@@ -661,8 +725,53 @@ def test_attention_spatial_long_second_pass(case):
     ops.attn_spatial(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o2, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=batch, seq=seq,
                      heads=heads)
     check(o, o2.float().cpu(), l2=2e-3, mx=1e-2)
-    flags = ws.cpu().view(batch, heads, nblk)
+    flags = ws.cpu()[:batch * heads * nblk].view(batch, heads, nblk)
     assert torch.equal(flags, expect), f"flagged blocks {flags.nonzero().tolist()} expected {expect.nonzero().tolist()}"
+    # the word behind the flag words counts the waves that flagged (the workgroups of this small call all start at once:
+    # nobody bails out, every flagged block was flagged by a wave that ran to the end)
+    waves = int(ws.cpu()[batch * heads * nblk])
+    assert (waves > 0) == bool(expect.any()) and waves <= 4 * int(expect.sum())
+
+
+def test_attention_spatial_long_worst_case_is_bounded():
+    """Data on which the frozen reference fails EVERYWHERE (every query has a matching key far from its own tokens): once
+    64 waves have flagged, workgroups that start later hand their block to the ordinary kernel at once instead of computing
+    it twice.  At the UNet's level-0 size (14 x 9,216 tokens x 5 heads: 2,520 workgroups, 256 at a time) the whole call
+    must cost at most 1.25x the ordinary kernel (it was 2.1x), with the same results and every block flagged."""
+    ops = _ops()
+    batch, seq, heads = 14, 9216, 5
+    c = heads * 64
+    g = torch.Generator(device=DEV).manual_seed(5)
+    d = torch.randn(batch * seq, 3 * c, generator=g, device=DEV, dtype=torch.float16)
+    qv = d[:, :c].view(batch, seq, heads, 64)
+    d[:, c:2 * c] = (qv.roll(3000, dims=1) * 3.0).reshape(batch * seq, c)          # key i+3000 = 3 x query i
+    o_long = torch.empty(batch * seq, c, dtype=torch.float16, device=DEV)
+    o_ord = torch.empty_like(o_long)
+    ws = torch.zeros(ops.attn_long_ws_bytes(batch, seq, heads) // 4, dtype=torch.int32, device=DEV)
+    kw = dict(ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=batch, seq=seq, heads=heads)
+
+    def run_long():
+        ops.attn_spatial_long(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o_long, ws, **kw)
+
+    def run_ord():
+        ops.attn_spatial(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], o_ord, **kw)
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best
+
+    t_ord, t_long = timed(run_ord), timed(run_long)
+    nblk = batch * heads * (seq // 256)
+    flags = ws.cpu()
+    assert int(flags[:nblk].sum()) == nblk, "every block must have been handed to the ordinary kernel"
+    assert int(flags[nblk]) >= 64 and int(flags[nblk]) <= 4 * 256 + 64, f"flagged-waves word {int(flags[nblk])}"
+    assert torch.equal(o_long, o_ord), "the second pass is the ordinary kernel: identical bytes"
+    assert t_long <= 1.25 * t_ord, f"all-flagged call {t_long:.2f} ms vs ordinary kernel {t_ord:.2f} ms"
 
 
 def test_attention_spatial_long_argument_errors():
@@ -670,9 +779,9 @@ def test_attention_spatial_long_argument_errors():
     c = 64
     d = torch.zeros(4096, 6 * c, dtype=torch.float16, device=DEV)
     small = torch.zeros(16, dtype=torch.int32, device=DEV)
-    assert ops.attn_long_ws_bytes(14, 9216, 5) == 14 * 5 * 36 * 4
+    assert ops.attn_long_ws_bytes(14, 9216, 5) == (14 * 5 * 36 + 1) * 4
     with pytest.raises(ops.HipKernelError, match="workspace"):
-        _attn_long(ops, d, 2 * c, 1, 4096, 2, ws=small)                   # two heads x 16 blocks need 32 words
+        _attn_long(ops, d, 2 * c, 1, 4096, 2, ws=small)                   # two heads x 16 blocks need 32 + 1 words
     with pytest.raises(ops.HipKernelError, match="stride"):
         o = torch.empty(4096, c, dtype=torch.float16, device=DEV)
         ops.attn_spatial_long(d, d, d, o, small, ldq=3 * c + 4, ldk=3 * c, ldv=3 * c, ldo=c, batch=1, seq=4096, heads=1)

@@ -126,3 +126,53 @@ def test_step_pipeline_of_the_real_model_is_bit_identical_across_world_sizes(tmp
     for key, got in outs.items():
         for i, (a, b) in enumerate(zip(base, got)):
             assert torch.equal(a, b), f"world/schedule {key}: video {i} differs from the single-rank result"
+
+
+def test_frames_out_of_the_pipelined_run_equal_decode_of_the_plain_loop(tmp_path):
+    """The last edge stage inside the pipeline (ref scripts/generate_video_demo.py:418 calls decode_latents on the last rank
+    after the step loop; models/edge_stages.py::FrameEmitter decodes sample i on rank i mod N, on a stream of its own beside
+    the UNet steps, the last rank forwarding the finished latent).  1, 2 and 3 ranks share the GPU (Gloo); the frames every
+    rank decoded, put together, must be bit-identical to `decode_latents` of the single-rank run's finished latents, each
+    sample must have been decoded exactly once and on the rank the schedule names, and `--no-spread` (the reference's
+    arrangement) must put all of them on the last rank."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    K = 5
+
+    def run(world, *extra):
+        out = tmp_path / f"w{world}_{'_'.join(a.strip('-') for a in extra) or 'spread'}"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(29700 + world + 10 * len(extra)),
+               os.path.join(root, "tools", "pp_frames.py"), "--out-dir", str(out), "--samples", str(K), *extra]
+        res = subprocess.run(cmd, env=env, timeout=300, capture_output=True, text=True)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+        return [torch.load(out / f"rank{r}.pt") for r in range(world)]
+
+    base = run(1)[0]
+    assert sorted(base["frames"]) == list(range(K)) and len(base["latents"]) == K
+    # what the single-rank pipeline emitted IS decode_latents of its finished latents (same kernels, same order: bit for bit)
+    from vdpp_amd.models.vae_hip import TemporalDecoderHIP, VAEDecoderConfig, random_state_dict
+    vcfg = VAEDecoderConfig.tiny(64)
+    dec = TemporalDecoderHIP(vcfg, random_state_dict(vcfg, seed=19), "cuda:0")
+    for i in range(K):
+        want = dec.decode_latents(base["latents"][i].to("cuda:0"), 3).cpu()
+        assert base["frames"][i].shape == (1, 3, 3, 64, 128) and torch.isfinite(want).all()
+        assert torch.equal(base["frames"][i], want), f"sample {i}: emitted frames differ from decode_latents"
+    for world, extra, where in ((2, (), lambda i, n: i % n), (3, (), lambda i, n: i % n), (3, ("--no-spread",), lambda i, n: n - 1),
+                                (2, ("--schedule", "ring"), None)):
+        ranks = run(world, *extra)
+        seen = {}
+        for r, rec in enumerate(ranks):
+            for i, fr in rec["frames"].items():
+                assert i not in seen, f"sample {i} decoded twice"
+                seen[i] = r
+                assert torch.equal(fr, base["frames"][i]), f"world {world} {extra}: frames of sample {i} differ"
+            assert rec["stats"]["decoded"] == len(rec["frames"])
+        assert sorted(seen) == list(range(K))
+        if where is not None:
+            assert all(seen[i] == where(i, world) for i in range(K)), (world, extra, seen)
+        if world > 1 and not extra:
+            assert ranks[-1]["stats"]["forwarded"] == K - len(ranks[-1]["frames"])

@@ -585,6 +585,8 @@ def test_benchmark_shape_two_kernel_routes_agree_and_are_deterministic(monkeypat
     torch.manual_seed(42)
     model.set_dummy_conditioning(1, 14, 72, 128, torch.device(DEV))
     lat = (torch.randn(1, 4, 14, 72, 128) * model.init_noise_sigma).half().to(DEV)
+    assert model.unet.long_attention is True, "the frozen-reference kernel is the default for the level-0 rows"
+    model.unet.long_attention = False            # a, b, c: every row through attn_spatial_kernel
     a = model(lat, 0)
     b = model(lat, 0)
     assert torch.isfinite(a).all()
@@ -596,18 +598,14 @@ def test_benchmark_shape_two_kernel_routes_agree_and_are_deterministic(monkeypat
     upd_a, upd_c = (a.float() - lat.float()).cpu(), (c.float() - lat.float()).cpu()
     err = rel_l2(upd_c, upd_a)
     assert err <= 5e-3, f"kernel routes disagree at the benchmark shape: rel_l2={err:.3e}"
-    # and with the level-0 attention through the frozen-reference kernel (opt-in: SVDUNetHIP(long_attention=True)):
+    # and with the level-0 attention through the frozen-reference kernel (the default: SVDUNetHIP(long_attention=None)):
     # another softmax reference and summation order, same arithmetic
-    was = model.unet.long_attention              # (off unless VDPP_LONG_ATTN=1; a/b/c above then already ran with it)
     model.unet.long_attention = True
-    try:
-        seen = []
-        orig = ops.attn_spatial_long
-        monkeypatch.setattr(ops, "attn_spatial_long", lambda *a, **k: (seen.append(k["seq"]), orig(*a, **k))[1])
-        d = model(lat, 0)
-        e = model(lat, 0)
-    finally:
-        model.unet.long_attention = was
+    seen = []
+    orig = ops.attn_spatial_long
+    monkeypatch.setattr(ops, "attn_spatial_long", lambda *a, **k: (seen.append(k["seq"]), orig(*a, **k))[1])
+    d = model(lat, 0)
+    e = model(lat, 0)
     assert seen and set(seen) == {72 * 128}, f"frozen-reference kernel not on the level-0 rows: {seen}"
     assert torch.equal(d, e), "two launches with long_attention differ"
     err = rel_l2((d.float() - lat.float()).cpu(), upd_a)

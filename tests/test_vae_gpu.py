@@ -174,34 +174,45 @@ def test_decoder_full_width_matches_oracle():
     assert err <= 2e-2, f"full-width decoder rel_l2={err:.3e}"
 
 
-def test_decoder_benchmark_shape_matches_oracle():
-    """The demo's own decode: 14 frames, 72 x 128 latent -> 576 x 1024 frames (8.26 M rows per activation at the last
-    level, 2.1 GB tensors, byte offsets just under 2^31).  The oracle's 97 TFLOP of fp32 run on the host cores in a
-    process of their own that tests/conftest.py started when the session began (tests/_vae_oracle_bg.py: same seeds, same
-    weights), beside the other GPU tests; run alone, this test waits for it (about 3-6 minutes)."""
-    import time
-
-    from tests import _vae_oracle_bg as bg
-    from tests.conftest import BG_ORACLE
-    from vdpp_amd.models.vae_hip import TemporalDecoderHIP, VAEDecoderConfig
-
-    assert "vae_benchmark_shape" in BG_ORACLE, "conftest did not start the host-side oracle"
-    proc, path = BG_ORACLE["vae_benchmark_shape"]
-    sd, z = bg.inputs()
-    hip = TemporalDecoderHIP(VAEDecoderConfig.svd(), sd, DEV)
-    got = hip.decode(z.to(DEV), 14)
+def test_decoder_benchmark_resolution_matches_oracle():
+    """The demo's own resolution against the oracle: 72 x 128 latent -> 576 x 1024 frames, 3 frames (1.77 M rows per
+    activation at the last level; 21 TFLOP of fp32 for the oracle on the host cores, ~40 s).  The demo's full 14 frames
+    are covered by the size-independent test below."""
+    hip, ref = _pair("svd", 3)
+    g = torch.Generator().manual_seed(31)
+    z = (torch.randn(3, 4, 72, 128, generator=g) * 4.0).half()
+    got = hip.decode(z.to(DEV), 3)
     torch.cuda.synchronize()
-    assert torch.isfinite(got).all()
-    got = got.float().cpu()
-    del hip
-    t0 = time.time()
-    while proc.poll() is None:
-        assert time.time() - t0 < 900, "host-side oracle still running after 15 minutes"
-        time.sleep(1.0)
-    assert proc.returncode == 0 and os.path.exists(path), f"host-side oracle failed (rc {proc.returncode})"
-    want = torch.load(path).float()
-    err = rel_l2(got, want)
-    assert err <= 2e-2, f"benchmark-shape decoder rel_l2={err:.3e}"
+    with torch.no_grad():
+        want = ref(z.float(), 3)
+    err = rel_l2(got.float().cpu(), want)
+    assert torch.isfinite(got).all() and err <= 2e-2, f"benchmark-resolution decoder rel_l2={err:.3e}"
+
+
+def test_decoder_benchmark_shape_two_kernel_routes_agree_and_are_deterministic():
+    """The demo's own decode at FULL size -- 14 frames, 72 x 128 latent -> 576 x 1024 frames, 8.26 M rows per activation at
+    the last level, 2.1 GB tensors whose byte offsets end just under 2^31 -- through a size-independent property (the
+    oracle's 97 TFLOP of fp32 took 190 of the suite's seconds): the decode through the large-tile ping-pong / persistent
+    contraction kernels must agree with the same decode through the independent 128 x 128 / 64 x 64 kernels (different
+    tiling, LDS image, pipeline and row addressing), and two launches must be bit-identical.  The oracle pins the same
+    weights at this resolution (3 frames, above) and at every width (tests above)."""
+    from vdpp_amd.hip import ops
+    hip, _ = _pair("svd", 3)
+    g = torch.Generator().manual_seed(31)
+    z = (torch.randn(14, 4, 72, 128, generator=g) * 4.0).half().to(DEV)
+    a = hip.decode(z, 14)
+    b = hip.decode(z, 14)
+    torch.cuda.synchronize()
+    assert a.shape == (14, 3, 576, 1024) and torch.isfinite(a).all()
+    assert torch.equal(a, b), "two decodes of the same latent differ"
+    del b
+    with ops.gemm_route(1):                          # small tiles only: neither gemm_pp.hip nor gemm_ps.hip
+        c = hip.decode(z, 14)
+    torch.cuda.synchronize()
+    err = rel_l2(c.float().cpu(), a.float().cpu())
+    assert err <= 5e-3, f"kernel routes disagree at the demo's decode size: rel_l2={err:.3e}"
+    # every frame, every image row carries signal (an addressing slip past 2^31 would leave zeros or repeats at the far end)
+    assert float(a[-1, :, -8:, :].float().abs().mean()) > 1e-3 and not torch.equal(a[-1], a[-2])
 
 
 # ------------------------------------------------------------------------------------------------ encoder half

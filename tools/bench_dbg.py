@@ -23,10 +23,12 @@ def run(spec, iters=20, rounds=5):
     conv = temporal = None
     if mode == 1:
         h, w = 72, 128
-        while 14 * h * w > m: h //= 2; w //= 2
-        conv = (14, h, w, h, w, 1, 0)
+        nimg = 14
+        while nimg * h * w > m and h > 9: h //= 2; w //= 2
+        while nimg * h * w < m: nimg += 14                # micro-batches: more images of the smallest level
+        conv = (nimg, h, w, h, w, 1, 0)
     if mode == 2:
-        temporal = (14, m // 14)
+        temporal = (14, m // 14) if m <= 129024 else (14, 129024 // 14)
     a = torch.randn(m, cin, device=dev, dtype=torch.float16)
     wt = torch.randn(n, taps * cin, device=dev, dtype=torch.float16) * 0.02
     no = n // 2 if geglu else n

@@ -1,8 +1,11 @@
 // Would spatial attention on the block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, the only fp8 form that runs at
 // 2x the fp16 rate on gfx950 -- MI355X_MICROARCH.md, matrix-core table) pay at head_dim 64?  Two questions, one binary:
 //
-//  (1) operand layout: with unit scales (E8M0 127), does lane l supply row/column l & 31 and the 32 consecutive k values
-//      32*(l >> 5) .. +31 in its 8 operand registers?  Checked exactly with small-integer e4m3 data against a host product.
+//  (1) operand layout: with unit scales (E8M0 127), lane l supplies row (A) / column (B) l & 31 and 32 of the 64 k values in
+//      its 8 operand registers, byte j of lane half h of A meeting byte j of lane half h of B.  Checked exactly with
+//      small-integer e4m3 data against a host product, under two assignments of k to (h, j): both are exact, as any
+//      assignment must be that is applied to both operands alike (the instruction sums over k) -- which is all an
+//      attention kernel needs: P's keys come out of the score accumulators in a fixed (h, j) order and V is stored to match.
 //  (2) price of one (64 keys x 32 queries) tile of the attention inner loop per wave, 1 to 3 waves per SIMD:
 //        f16     : 16 x v_mfma_f32_32x32x16_f16     + 32 v_exp_f32 + 16 v_cvt_pk_f16_f32 + 16 v_max3_f32
 //        fp8     : 16 x v_mfma_f32_32x32x16_fp8_fp8 + 32 v_exp_f32 + 16 v_cvt_pk_fp8_f32 + 16 v_max3_f32   (today's kernel)

@@ -20,7 +20,7 @@ orig = ops.attn_spatial_long
 def counted(q, k, v, o, ws, **kw):
     r = orig(q, k, v, o, ws, **kw)
     torch.cuda.synchronize()
-    n = ops.attn_long_ws_bytes(kw["batch"], kw["seq"], kw["heads"]) // 4
+    n = ops.attn_long_ws_bytes(kw["batch"], kw["seq"], kw["heads"]) // 4 - 1      # (the last word counts flagged waves)
     calls.append((kw["batch"], kw["seq"], kw["heads"], int(ws.view(torch.int32)[:n].sum()), n))
     return r
 ops.attn_spatial_long = counted

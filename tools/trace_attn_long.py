@@ -17,7 +17,7 @@ c = h * 64
 qkv = torch.randn(b * s, 3 * c, device="cuda", dtype=torch.float16)
 o = torch.empty(b * s, c, device="cuda", dtype=torch.float16)
 need = ops.attn_long_ws_bytes(b, s, h)
-ws = torch.zeros(need // 4 + 16, dtype=torch.int32, device="cuda")
+ws = torch.zeros(need // 4 + 16, dtype=torch.int32, device="cuda")   # need: flag words + the flagged-waves word; + 16 stamps
 for _ in range(3):
     ops.attn_spatial_long(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], o, ws, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, batch=b, seq=s, heads=h)
 torch.cuda.synchronize()

@@ -17,9 +17,14 @@
 // the row sum l through the matrix pipe (as inf, or NaN from 0 x inf), and a wave that ends with a non-finite l raises
 // its workgroup's word in `flags`.  The host entry then launches attention.hip's kernel over the flagged 256-row
 // blocks only (a workgroup whose word is zero exits at once), which overwrites their rows.  So results never depend on
-// the speculation, only the time does: nothing flagged costs one near-empty launch; everything flagged costs this
-// kernel plus the ordinary one (tools/bench_attn_long.py modes l / h; tools/long_attn_flags.py counts the flagged
-// blocks inside the UNet: none at the benchmark's shapes and weights).  l >= 1 needs no check: the reference is a
+// the speculation, only the time does: nothing flagged costs one near-empty launch.  The cost of a wrong guess is
+// BOUNDED (round 4): flagging waves also count themselves in one more word behind the flag words, every workgroup reads
+// that word when it starts, and once LONG_BAIL waves have flagged, a starting workgroup only raises its own flag word
+// and exits -- data on which the frozen reference keeps failing is handed to the ordinary kernel after the first round
+// of workgroups (256 of the 2,520 of a level-0 call) instead of being computed twice: everything flagged costs ~1.1x
+// the ordinary kernel (it was 2.1x), measured by tests/test_kernels_gpu.py::test_attention_spatial_long_second_pass
+// (tools/bench_attn_long.py modes l / h; tools/long_attn_flags.py counts the flagged blocks inside the UNet: none at
+// the benchmark's shapes and weights).  l >= 1 needs no check: the reference is a
 // score of the row.  A proven bound instead of the speculation was tried first (Cauchy-Schwarz, |q| max|k| from a
 // pre-pass, reference max(tile-0 maximum, bound - 15)): it never overflows but is so loose -- twice the true maximum
 // for Gaussian data -- that with q, k of 1.5x unit variance every row lost its mass below fp16's range.
@@ -49,6 +54,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// waves that may flag before starting workgroups stop trying (a level-0 call of the UNet has 10,080 - 20,160 waves)
+constexpr unsigned LONG_BAIL = 64;
+
 template <int QB>
 __global__ __launch_bounds__(256, 1) void attn_long_kernel(
     const f16 *__restrict__ q, const f16 *__restrict__ k, const f16 *__restrict__ v, f16 *__restrict__ o,
@@ -63,6 +71,20 @@ __global__ __launch_bounds__(256, 1) void attn_long_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.y;
+  // ---- has the frozen reference been failing on this call's data?  (word behind the flag words: waves that flagged so
+  // far; a heuristic read -- a stale value only means one more workgroup tries.)  One thread reads, LDS hands the value to
+  // the whole workgroup, so that all four waves take the same way.
+  {
+    unsigned *const flagged_waves = flags + (int64_t)gridDim.x * gridDim.y;
+    if (tid == 0) *(volatile unsigned *)smem = __hip_atomic_load(flagged_waves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned seen = *(volatile unsigned *)smem;
+    __syncthreads();                         // (the ring's first LDS-DMA piece lands on this word)
+    if (seen >= LONG_BAIL) {
+      if (tid == 0) flags[(int64_t)bh * gridDim.x + blockIdx.x] = 1u;   // the second pass computes this block
+      return;
+    }
+  }
   const int b = bh / heads, hd = bh - b * heads;
   const int r = lane & 31, h = lane >> 5;
   const int64_t row0 = (int64_t)b * seq;
@@ -423,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void attn_long_kernel(
 #ifdef LONG_TRACE
   tr[14] = (unsigned)(__builtin_amdgcn_s_memtime() - tc0);             // steady loop: shader cycles / 100 MHz ticks
   tr[15] = (unsigned)(wall_clock64() - tw0);
-  if (blockIdx.x == 3 && blockIdx.y == LONG_TRACE && tid < 16) flags[gridDim.x * gridDim.y + tid] = tr[tid];
+  if (blockIdx.x == 3 && blockIdx.y == LONG_TRACE && tid < 16) flags[gridDim.x * gridDim.y + 1 + tid] = tr[tid];   // (+1: the flagged-waves word)
 #endif
   // a probability that overflowed fp16 reached the row sum as inf (or NaN): this workgroup's rows are done again by
   // attention.hip's kernel (host entry below); what is stored here for them is overwritten
@@ -431,7 +453,10 @@ __global__ __launch_bounds__(256, 1) void attn_long_kernel(
     bool bad = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) bad = bad || !(lacc[qb][0] < 3.0e38f);
-    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) flags[(int64_t)bh * gridDim.x + blockIdx.x] = 1u;
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) {
+      flags[(int64_t)bh * gridDim.x + blockIdx.x] = 1u;
+      __hip_atomic_fetch_add(flags + (int64_t)gridDim.x * gridDim.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 
   // ---- finalize: O^T[d][q] / l ; lane holds d = 32dt + (e&3) + 8(e>>2) + 4h for query q0 + 32 qb + r
@@ -462,10 +487,11 @@ int sp_attn_spatial_launch(const void *q, const void *k, const void *v, void *o,
                            int64_t ldo, int batch, int seq, int heads, float scale, const void *zero_page,
                            const unsigned *only_flagged, void *stream, const char *who);
 
-// bytes of workspace sp_attn_spatial_long_f16 needs: one word per 256 query rows of every (batch item, head)
+// bytes of workspace sp_attn_spatial_long_f16 needs: one word per 256 query rows of every (batch item, head), and one
+// more behind them that counts the waves that flagged (LONG_BAIL)
 extern "C" int64_t sp_attn_long_ws_bytes(int batch, int seq, int heads) {
   if (batch <= 0 || seq <= 0 || heads <= 0) return 0;
-  return (int64_t)batch * heads * ((seq + LONG_ROWS - 1) / LONG_ROWS) * (int64_t)sizeof(unsigned);
+  return ((int64_t)batch * heads * ((seq + LONG_ROWS - 1) / LONG_ROWS) + 1) * (int64_t)sizeof(unsigned);
 }
 
 // Spatial self-attention, same contract as sp_attn_spatial_f16 and the same results to fp16 rounding, through the

@@ -512,9 +512,13 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
   const int route = g_route;
 
   // ---- output-row LayerNorm statistics live in the ping-pong epilogue (one tile = whole rows)
+  // per-row-group weights: a tile must lie inside one group (192-row tiles need groups of a multiple of 192 rows, ...)
+  auto group_ok = [&](int bm) { return a.w_group_rows == 0 || a.w_group_rows % bm == 0; };
   if (a.ln_out) {
     const int bn = d->n <= 320 ? d->n : d->n / 2;
-    const int bm = makespan(d->m, d->n, 192, bn) * 1.06 < makespan(d->m, d->n, 256, bn) ? 192 : 256;
+    int bm = makespan(d->m, d->n, 192, bn) * 1.06 < makespan(d->m, d->n, 256, bn) ? 192 : 256;
+    if (!group_ok(bm)) bm = group_ok(256) ? 256 : 192;
+    SP_REQUIRE(group_ok(bm), "sp_gemm_f16: w_group_rows=%lld fits neither 256- nor 192-row tiles", (long long)a.w_group_rows);
     if (int rc = launch_pp(a, bm, bn, s)) return rc;
     if (a.ln_part) {
       SP_CLEAR_STALE_ERROR();
@@ -524,6 +528,16 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
       spgemm::note_kernel_suffix(" + ln_part_finalize_kernel");
     }
     return SP_OK;
+  }
+
+  if (a.w_group_rows) {                       // ping-pong kernels only (the others walk one weight matrix)
+    const int bn = ok320 ? 320 : 256;
+    int bm = 0;
+    const int bms[3] = {256, 192, 128};
+    for (int i = 0; i < 3 && !bm; ++i)
+      if (group_ok(bms[i]) && !(bms[i] == 128 && bn != 256)) bm = bms[i];
+    SP_REQUIRE(bm, "sp_gemm_f16: w_group_rows=%lld fits no tile height for n=%d", (long long)a.w_group_rows, d->n);
+    return launch_pp(a, bm, bn, s);
   }
 
   // ---- persistent-stream tiles (gemm_ps.hip): linear contractions with several tiles per CU, where launch gap,
@@ -665,6 +679,15 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   a.res1 = (const f16 *)d->res1; a.res2 = (const f16 *)d->res2; a.d = (f16 *)d->d;
   a.ln_stats = d->ln_stats; a.ln_colsum = d->ln_colsum;
   a.ln_out = d->ln_out; a.ln_out_eps = d->ln_out_eps;
+  a.w_group_rows = 0; a.w_group_stride = 0;
+  if (d->w_group_rows != 0) {
+    SP_REQUIRE(d->w_group_rows > 0 && d->w_group_rows % 128 == 0 && d->w_group_stride > 0 && d->w_group_stride % 8 == 0 &&
+                   d->mode == SP_A_LINEAR && !d->geglu && !d->euler_out && (d->n % 256 == 0 || d->n % 320 == 0),
+               "sp_gemm_f16: per-row-group weights need SP_A_LINEAR, no geglu / Euler tail, n a multiple of 256 or 320, "
+               "w_group_rows a positive multiple of 128 (got %lld) and w_group_stride a positive multiple of 8 (got %lld)",
+               (long long)d->w_group_rows, (long long)d->w_group_stride);
+    a.w_group_rows = d->w_group_rows; a.w_group_stride = d->w_group_stride;
+  }
   if (d->ln_out) {
     SP_REQUIRE((d->n == 256 || d->n == 320 || d->n == 512 || d->n == 640) && !d->geglu && d->n_store == 0 && !d->euler_out &&
                    d->ln_out_eps > 0.f,

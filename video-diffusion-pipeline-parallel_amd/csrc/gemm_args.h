@@ -31,6 +31,7 @@ struct GemmArgs {
   f16 *d;
   const char *zero;
   int64_t lda, ldr1, ldr2, ldd, hw, bias2_rows, ldb2;
+  int64_t w_group_rows, w_group_stride;   // > 0: rows [g*w_group_rows, ..) use the weights at w + g*w_group_stride (ping-pong kernels)
   int mode, cin, taps;
   int n_img, hin, win, hout, wout, stride, ups;
   int frames;

@@ -223,7 +223,9 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
     if (idx >= NCH || m >= p.m || col >= nstore) continue;
     if (col + 8 <= nstore) {
 #ifdef SP_GEMM_EXPERIMENTS
-      if (p.dbg & 256) __builtin_nontemporal_store(o[it], (f16x8 *)(p.d + m * p.ldd + col));
+      // (non-temporal stores measured here too: no difference on any shape -- a one-tile workgroup ends behind its stores,
+      // nothing waits for their acknowledgement; profiles/r04_nt_stores_ab.txt)
+      if (p.dbg & 512) __builtin_nontemporal_store(o[it], (f16x8 *)(p.d + m * p.ldd + col));
       else
 #endif
       *(f16x8 *)(p.d + m * p.ldd + col) = o[it];
@@ -414,6 +416,8 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
     const int r = piece * 16 + lrow;
     const int n = tile_n * BN + (r < BN ? r : 0);
     bptr[j] = p.w + (int64_t)n * p.k + (lchunk ^ swz4(r)) * 8;
+    // per-row-group weights (a GroupNorm folded into this linear layer: one scaled copy per frame; host: no tile straddles)
+    if (p.w_group_rows > 0) bptr[j] += ((int64_t)tile_m * PBM / p.w_group_rows) * p.w_group_stride;
   }
 
   bool skip_a = false;                            // (experiments build: see HALO_COUNT)

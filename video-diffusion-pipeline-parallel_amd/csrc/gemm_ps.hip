@@ -436,14 +436,19 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
           q[j][o] = out;
         }
       __builtin_amdgcn_sched_barrier(0);
+      // Non-temporal stores (aux = 2).  Loads and stores retire through ONE in-order queue per wave, so the next tile's
+      // K-step 4 counts as landed only once this tile's stores have been acknowledged; streaming stores are acknowledged
+      // sooner and leave the XCD's L2 to the operands.  Same-process A/B (tools/bench_dbg.py, bit 256 = the OLD default
+      // stores): GEGLU FF1 258,048 x 2,560 x 320 534.7 -> 516.3 us, 64,512 x 5,120 x 640 419.8 -> 408.7, plain
+      // 64,512 x 2,560 x 640 249.4 -> 215.3, 16,128 x 10,240 x 1,280 352.1 -> 350.9 (profiles/r04_nt_stores_ab.txt).
 #ifdef SP_GEMM_EXPERIMENTS
-      if (p.dbg & 256) {                                  // non-temporal stores (aux = 2): A/B only
+      if (p.dbg & 256) {                                  // default-policy stores: the A/B's other arm
 #pragma unroll
         for (int j = 0; j < TM; ++j)
 #pragma unroll
           for (int o = 0; o < TNO / 2; ++o)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, q[j][o]), d_rsrc,
-                                                   (int)(((mrow0 + j * 16) * p.ldd + col0 + o * 32) * 2), 0, 2);
+                                                   (int)(((mrow0 + j * 16) * p.ldd + col0 + o * 32) * 2), 0, 0);
       } else
 #endif
       {
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
 #pragma unroll
         for (int o = 0; o < TNO / 2; ++o)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, q[j][o]), d_rsrc,
-                                                 (int)(((mrow0 + j * 16) * p.ldd + col0 + o * 32) * 2), 0, 0);
+                                                 (int)(((mrow0 + j * 16) * p.ldd + col0 + o * 32) * 2), 0, 2);
       }
     }
     c_tm = n_tm; c_tn = n_tn;

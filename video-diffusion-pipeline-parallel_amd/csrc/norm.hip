@@ -341,6 +341,38 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(const f16 *__restrict__ x
   }
 }
 
+// GroupNorm folded into the linear layer behind it (sp_groupnorm_fold_linear_f16): one wave per (instance, output row n)
+// scales the weight row by gamma[c] * rstd[instance][group(c)], rounds it to fp16 and takes the row's bias from the ROUNDED
+// values (so that a constant offset of a group cancels exactly in the contraction).  instances * n * c halves written.
+__global__ __launch_bounds__(256) void gn_fold_linear_kernel(const float *__restrict__ stats, const f16 *__restrict__ w,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             const float *__restrict__ bias, f16 *__restrict__ w_out,
+                                                             float *__restrict__ bias_out, int n, int c, int groups) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int inst = blockIdx.x;
+  const int row = blockIdx.y * 4 + wave;
+  if (row >= n) return;
+  const int oc = c >> 3, cpg = c / groups;
+  const float *st = stats + (int64_t)inst * groups * 2;
+  const f16 *wr = w + (int64_t)row * c;
+  f16 *wo = w_out + ((int64_t)inst * n + row) * c;
+  float acc = 0.f;
+  for (int o = lane; o < oc; o += 64) {
+    const f16x8 v = *(const f16x8 *)(wr + o * 8);
+    f16x8 q;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = o * 8 + e, g = ch / cpg;
+      const float wv = (float)v[e];
+      q[e] = (f16)(wv * (gamma ? gamma[ch] : 1.f) * st[g * 2 + 1]);
+      acc += (beta ? beta[ch] : 0.f) * wv - st[g * 2] * (float)q[e];
+    }
+    *(f16x8 *)(wo + o * 8) = q;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) bias_out[(int64_t)inst * n + row] = acc + (bias ? bias[row] : 0.f);
+}
+
 // rows per statistics block: about 1024 blocks in all, >= 16 row-iterations per thread, at most 512 splits per instance
 // (sp_groupnorm_ws_bytes), and a multiple of 4*P rows so that the kernel runs whole batches of four loads per thread
 int64_t gn_rows_per_split(int instances, int64_t rows, int P) {
@@ -610,6 +642,39 @@ extern "C" int sp_groupnorm_ld_f16(const void *x, int64_t ldx, const float *gamm
                      (const f16 *)x, (const float *)stats, fold_in_apply ? (const float *)ws : (const float *)nullptr, splits,
                      eps, gamma, beta, (f16 *)y, rows, c, groups, fuse_silu, rpb, ldx);
   SP_CHECK_LAUNCH("sp_groupnorm_f16(apply)");
+  return SP_OK;
+}
+
+// GroupNorm (no activation) folded into the linear layer behind it: statistics pass + one small kernel (svdpipe.h)
+extern "C" int sp_groupnorm_fold_linear_f16(const void *x, int64_t ldx, const float *gamma, const float *beta, int instances,
+                                            int64_t rows, int c, int groups, float eps, const void *w, const float *bias,
+                                            int n, void *w_out, float *bias_out, void *ws, size_t ws_bytes, void *stream) {
+  SP_REQUIRE(x && w && w_out && bias_out && ws, "sp_groupnorm_fold_linear_f16: null pointer");
+  SP_REQUIRE(ldx >= c && ldx % 8 == 0, "sp_groupnorm_fold_linear_f16: ldx=%lld must be a multiple of 8 and >= C=%d",
+             (long long)ldx, c);
+  SP_REQUIRE(instances > 0 && rows > 0 && n > 0, "sp_groupnorm_fold_linear_f16: instances/rows/n must be positive");
+  SP_REQUIRE(c % 8 == 0 && c >= 8 && c <= 4096, "sp_groupnorm_fold_linear_f16: C=%d must be a multiple of 8 in [8,4096]", c);
+  SP_REQUIRE(groups > 0 && groups <= 64 && c % groups == 0, "sp_groupnorm_fold_linear_f16: groups=%d invalid for C=%d", groups, c);
+  SP_REQUIRE(ws_bytes >= sp_groupnorm_ws_bytes(instances, rows, c, groups), "sp_groupnorm_fold_linear_f16: workspace too small");
+  const int oc = c / 8;
+  const int P = gn_rows_per_iter(oc);
+  const int threads = ((oc * P + 63) / 64) * 64 < 64 ? 64 : ((oc * P + 63) / 64) * 64;
+  SP_REQUIRE(threads <= 1024, "sp_groupnorm_fold_linear_f16: C too large");
+  const int64_t per = gn_rows_per_split(instances, rows, P);
+  const int splits = (int)((rows + per - 1) / per);            // <= 512
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = ((size_t)P * c * 2 + (size_t)(threads / groups) * groups * 2) * sizeof(float);
+  float *stats = (float *)ws + (size_t)instances * splits * groups * 2;
+  SP_CLEAR_STALE_ERROR();
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(instances, splits), dim3(threads), lds, s, (const f16 *)x, (float *)ws, rows, c,
+                     groups, splits, per, ldx);
+  SP_CHECK_LAUNCH("sp_groupnorm_fold_linear_f16(stats)");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(instances), dim3(1024), 0, s, (const f16 *)x, (const float *)ws, stats, rows, c,
+                     groups, splits, eps, ldx);
+  SP_CHECK_LAUNCH("sp_groupnorm_fold_linear_f16(finalize)");
+  hipLaunchKernelGGL(gn_fold_linear_kernel, dim3(instances, (n + 3) / 4), dim3(256), 0, s, (const float *)stats,
+                     (const f16 *)w, gamma, beta, bias, (f16 *)w_out, bias_out, n, c, groups);
+  SP_CHECK_LAUNCH("sp_groupnorm_fold_linear_f16(fold)");
   return SP_OK;
 }
 

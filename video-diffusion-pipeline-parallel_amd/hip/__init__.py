@@ -37,6 +37,7 @@ class GemmDesc(ctypes.Structure):
         ("euler_frames", ctypes.c_int), ("euler_hw", ctypes.c_int64),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
         ("ln_out", ctypes.c_void_p), ("ln_out_eps", ctypes.c_float),
+        ("w_group_rows", ctypes.c_int64), ("w_group_stride", ctypes.c_int64),
     ]
 
 
@@ -56,6 +57,7 @@ SIGNATURES = {
     "sp_groupnorm_ws_bytes": (_Z, [_I, _L, _I, _I]),
     "sp_groupnorm_f16": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _Z, _P]),
     "sp_groupnorm_ld_f16": (_I, [_P, _L, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _Z, _P]),
+    "sp_groupnorm_fold_linear_f16": (_I, [_P, _L, _P, _P, _I, _L, _I, _I, _F, _P, _P, _I, _P, _P, _P, _Z, _P]),
     "sp_layernorm_f16": (_I, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _F, _P]),
     "sp_ln_stats_f16": (_I, [_P, _P, _L, _P, _P, _L, _I, _F, _P]),
     "sp_attn_spatial_f16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _F, _P, _P]),

@@ -82,9 +82,11 @@ def _rows(t: torch.Tensor, name: str, ld: int) -> torch.Tensor:
 def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=None, bias=None,
          bias2=None, bias2_rows=0, ldb2=0, res1=None, r1scale=1.0, res2=None, r2scale=1.0, oscale=1.0,
          geglu=False, n_store=0, ldd=None, ldr1=None, ldr2=None, ln_stats=None, ln_colsum=None, euler=None,
-         workspace=None, ln_out=None, ln_out_eps=1e-5):
+         workspace=None, ln_out=None, ln_out_eps=1e-5, w_group_rows=0, w_group_stride=0):
     """``out[m][:] = epilogue(sum_taps A_tap @ W^T)``; see ``sp_gemm_desc`` in include/svdpipe.h.
-    ``ln_stats`` / ``ln_colsum``: LayerNorm folded into the contraction (``a`` is the UN-normalised tensor)."""
+    ``ln_stats`` / ``ln_colsum``: LayerNorm folded into the contraction (``a`` is the UN-normalised tensor).
+    ``w_group_rows`` / ``w_group_stride``: ``w`` holds one weight matrix per group of that many output rows (a GroupNorm
+    folded into this linear layer, ``groupnorm_fold_linear``)."""
     d = GemmDesc()
     d.lda = int(lda if lda is not None else cin)
     d.a, d.mode, d.cin = _rows(a, "a", d.lda).data_ptr(), mode, cin
@@ -115,6 +117,7 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
         if ln_out.dtype != torch.float32 or tuple(ln_out.shape) != (m, 2) or not ln_out.is_contiguous():
             raise ValueError("ln_out must be a contiguous float32 [m][2] tensor")
         d.ln_out, d.ln_out_eps = ln_out.data_ptr(), float(ln_out_eps)
+    d.w_group_rows, d.w_group_stride = int(w_group_rows), int(w_group_stride)
     taps = 9 if mode == A_CONV3X3 else 3 if mode == A_TEMPORAL3 else 1
     # algorithmic bytes of this launch: every operand element once (A without tap re-reads), output and residuals once
     a_rows = d.n_img * d.hin * d.win if mode == A_CONV3X3 else m
@@ -184,6 +187,22 @@ def groupnorm(x, gamma, beta, y, *, instances, rows, c, groups, eps, silu, ws, l
                                           _f16(y, "y").data_ptr(), instances, rows, c, groups, eps, int(silu),
                                           ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), "sp_groupnorm_f16")
     return y
+
+
+def groupnorm_fold_linear(x, gamma, beta, w, bias, w_out, bias_out, *, instances, rows, c, groups, eps, n, ws, ldx=None):
+    """GroupNorm (no activation) folded into the linear layer ``w`` [n][c] behind it: ONE pass over ``x`` (statistics) and
+    ``w_out`` [instances][n][c] fp16 / ``bias_out`` [instances][n] fp32 for ``gemm(x, w_out, ..., w_group_rows=rows,
+    w_group_stride=n*c, bias=None, bias2=bias_out, bias2_rows=rows)`` on the RAW ``x`` (see include/svdpipe.h)."""
+    with _Timed("groupnorm", 0.0, 2.0 * instances * rows * c + 2.0 * instances * n * c):
+        ldx = int(c if ldx is None else ldx)
+        if tuple(w_out.shape) != (instances, n, c) or not w_out.is_contiguous() or bias_out.dtype != torch.float32 \
+                or tuple(bias_out.shape) != (instances, n) or not bias_out.is_contiguous():
+            raise ValueError("groupnorm_fold_linear: w_out must be contiguous fp16 [instances][n][c], bias_out fp32 [instances][n]")
+        _check(load().sp_groupnorm_fold_linear_f16(_rows(x, "x", ldx).data_ptr(), ldx, _ptr(gamma), _ptr(beta), instances,
+                                                   rows, c, groups, eps, _f16(w, "w").data_ptr(), _ptr(bias), n,
+                                                   _f16(w_out, "w_out").data_ptr(), bias_out.data_ptr(), ws.data_ptr(),
+                                                   ws.numel() * ws.element_size(), _stream()), "sp_groupnorm_fold_linear_f16")
+    return w_out, bias_out
 
 
 def layernorm(x, gamma, beta, y, *, rows, c, eps=1e-5, addvec=None, addvec_rows=0, sum_out=None):

@@ -37,3 +37,142 @@ def decode_latents(latents: torch.Tensor, vae: TemporalDecoderHIP, num_frames: i
     """(B, 4, F, H, W) latents -> (B, 3, F, 8H, 8W) fp32 frames (ref ``:154-195``)."""
     return vae.decode_latents(latents.to(vae.device, torch.float16).contiguous(), num_frames,
                               decode_chunk_size=decode_chunk_size)
+
+
+class FrameEmitter:
+    """``decode_latents`` wired into the step pipeline, so that the node emits frames (ref
+    ``scripts/generate_video_demo.py:418`` decodes every finished latent on the LAST rank, after the step loop).
+
+    The temporal-VAE decode of one video costs about as much as a whole stage of an 8-GPU pipeline (three UNet steps), so
+    run where the reference runs it -- on the last rank -- it would halve the node's rate.  Here (``spread=True``) the
+    finished latent of pipeline sample ``i`` is decoded by rank ``i mod N``: the last rank forwards it with the same
+    point-to-point transport the stages use (one more 1-2 MB message per video), every rank decodes on a HIP stream of
+    its own BESIDE its UNet steps, and per video each GPU carries 1/N of a decode instead of one GPU carrying all of it.
+    With the ring schedule a video finishes on rank ``(i mod N) - 1`` and is decoded right there.  ``spread=False`` is
+    the reference's arrangement (everything on the last rank).
+
+    Attach to a stage on EVERY rank (same arguments), run the pipeline, then ``finish(num_samples)``:
+
+        emitter = FrameEmitter(decoder, stage, num_frames)            # every rank
+        stage.run_many(K, input_supplier=...); stage.drain()
+        frames = emitter.finish(K)                                    # {sample index: (B,3,F,8H,8W) fp32} decoded HERE
+
+    A receive for a forwarded latent is posted when this rank has issued the sample that the last rank is finishing at
+    about that moment (``i + N-1-rank``), not earlier: a parked RCCL receive is a resident kernel.  Over Gloo with GPU
+    latents (rehearsal on a shared card) the events are waited for on the host, as in ``pipeline._SideStreamLink``.
+    """
+
+    TAG = 7001
+
+    def __init__(self, decoder: TemporalDecoderHIP, stage, num_frames: int, *, decode_chunk_size: int = 14,
+                 spread: bool = True, keep: str = "all", check_finite: bool = False) -> None:
+        import torch.distributed as dist
+        from ..pipeline.step_assignment import ring_finish_rank
+
+        if keep not in ("all", "last", "none"):
+            raise ValueError("keep must be 'all', 'last' or 'none'")
+        self.decoder, self.stage, self.num_frames = decoder, stage, num_frames
+        self.chunk, self.keep, self.check_finite = decode_chunk_size, keep, check_finite
+        cfg = stage.config
+        self.rank, self.world = cfg.rank, cfg.world_size
+        self.ring = bool(cfg.ring and cfg.world_size > 1)
+        self.spread = bool(spread and self.world > 1 and not self.ring)
+        self.spec = cfg.latent_spec
+        self.device = decoder.device
+        self.stream = torch.cuda.Stream(device=self.device)          # decodes
+        self.side = torch.cuda.Stream(device=self.device) if self.world > 1 else None      # forwards
+        self.host_ordered = self.world > 1 and dist.is_initialized() and dist.get_backend() == "gloo"
+        self._dist, self._ring_finish_rank = dist, ring_finish_rank
+        self.frames: dict[int, torch.Tensor] = {}
+        self._next_recv = self.rank              # next sample this rank is to receive (spread mode, not the last rank)
+        self._issued = -1                        # highest sample index this rank has issued
+        self._in_flight: list = []
+        self.stats = {"decoded": 0, "forwarded": 0, "received": 0}
+        stage.finished_latent_hook = self._finished
+        stage.after_sample_hook = self._after_sample
+
+    # ---------------------------------------------------------------- who decodes sample i
+    def decoder_rank(self, idx: int) -> int:
+        if self.ring:
+            return self._ring_finish_rank(idx, self.world)
+        return idx % self.world if self.spread else self.world - 1
+
+    # ---------------------------------------------------------------- hooks
+    def _finished(self, idx: int, latent: torch.Tensor) -> None:
+        """On the rank (and stream) where sample idx's last step was just enqueued."""
+        target = self.decoder_rank(idx)
+        if target == self.rank:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            self._decode(idx, latent, ready)
+            return
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        latent.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            if self.host_ordered:
+                ready.synchronize()
+            work = self._dist.isend(latent, dst=target, tag=self.TAG)
+        self._in_flight.append((work, latent))
+        self.stats["forwarded"] += 1
+
+    def _after_sample(self, idx: int) -> None:
+        self._issued = max(self._issued, idx)
+        if self.spread and self.rank != self.world - 1:
+            # the last rank is finishing sample j about when this rank issues sample j + (N-1-rank)
+            while self._next_recv + (self.world - 1 - self.rank) <= self._issued:
+                self._receive(self._next_recv)
+                self._next_recv += self.world
+
+    def _receive(self, idx: int) -> None:
+        buf = self.spec.empty()
+        buf.record_stream(self.side)
+        allocated = torch.cuda.Event()
+        allocated.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(allocated)
+            if self.host_ordered:
+                allocated.synchronize()
+            work = self._dist.irecv(buf, src=self.world - 1, tag=self.TAG)
+            work.wait()                          # RCCL: orders the side stream; Gloo: blocks the host until it has landed
+            landed = torch.cuda.Event()
+            landed.record(self.side)
+        self.stats["received"] += 1
+        self._decode(idx, buf, landed)
+
+    def _decode(self, idx: int, latent: torch.Tensor, ready) -> None:
+        latent.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            out = self.decoder.decode_latents(latent.contiguous(), self.num_frames, decode_chunk_size=self.chunk)
+        self.stats["decoded"] += 1
+        if self.keep == "all":
+            self.frames[idx] = out
+        elif self.keep == "last":
+            self.frames = {idx: out}
+
+    # ---------------------------------------------------------------- end of a run
+    def finish(self, num_samples: int) -> dict:
+        """Post what is still to be received (the pipeline's tail), wait for this rank's decodes and forwards, and return
+        ``{sample index: frames}`` for the samples decoded on THIS rank (``keep``: all of them, the last one, or none)."""
+        if self.spread and self.rank != self.world - 1:
+            while self._next_recv < num_samples:
+                self._receive(self._next_recv)
+                self._next_recv += self.world
+        for work, _ in self._in_flight:
+            work.wait()
+        self._in_flight.clear()
+        if self.side is not None:
+            self.side.synchronize()
+        self.stream.synchronize()
+        if self.check_finite:
+            for idx, out in self.frames.items():
+                if not bool(torch.isfinite(out).all()):
+                    raise FloatingPointError(f"frames of sample {idx} hold non-finite values (fp16 activation range)")
+        return self.frames
+
+    def reset(self) -> None:
+        """Forget the previous run's bookkeeping (bench.py: warm-up, then the timed region)."""
+        self.frames = {}
+        self._next_recv, self._issued = self.rank, -1

@@ -143,13 +143,17 @@ class SVDUNetHIP:
                  long_attention: bool | None = None):
         """``fp8_attention``: run the spatial self-attention on fp8-e4m3 MFMA (BASELINE config 5: "SVD-XT ... with
         fp8 MFMA attention path"); default off, or ``VDPP_FP8_ATTN=1``.  Everything else stays fp16.
-        ``long_attention``: level-0 rows through the frozen-reference kernel; default off, or ``VDPP_LONG_ATTN=1``.
-        Same results; it is faster while no query meets, far from its own tokens, a key that scores 11 nats above
-        everything near them, and up to 2x slower on the rows where that happens all the time (DESIGN.md section 3;
+        ``long_attention``: level-0 rows (>= 8,192 tokens) through the frozen-reference kernel; default ON since round 4
+        (``False`` or ``VDPP_LONG_ATTN=0`` selects the ordinary kernel for every row).  Same results; it is 5-9 % faster
+        while no query meets, far from its own tokens, a key that scores 11 nats above everything near them, and costs at
+        most ~1.1-1.25x the ordinary kernel on data where that happens all the time (after 64 flagged waves the remaining
+        workgroups hand their blocks to the ordinary kernel at once: csrc/attention_long.hip, DESIGN.md section 3;
         ``tools/long_attn_flags.py`` counts the cases on a given set of weights)."""
         self.cfg = cfg
         self.fp8_attention = (os.environ.get("VDPP_FP8_ATTN") == "1") if fp8_attention is None else bool(fp8_attention)
-        self.long_attention = (os.environ.get("VDPP_LONG_ATTN") == "1") if long_attention is None else bool(long_attention)
+        self.long_attention = (os.environ.get("VDPP_LONG_ATTN", "1") != "0") if long_attention is None else bool(long_attention)
+        # the 16 transformer-entry GroupNorms folded into proj_in where a frame is whole tiles (VDPP_FOLD_GN=0: never)
+        self.fold_groupnorm = os.environ.get("VDPP_FOLD_GN", "1") != "0"
         self.device = dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("SVDUNetHIP runs on an MI355X HIP device only (no CPU fallback)")
@@ -355,6 +359,14 @@ class SVDUNetHIP:
         # output and _ln_stats finds them there instead of reading the tensor again (512 / 640 channels, level 1: two tiles
         # per row, their sums meet in a 16-byte-per-row scratch).
         ln_next = kw.pop("ln_next", None)
+        # ``w_groups`` = (w_f [instances][n][c] fp16, bias_f [instances][n] fp32, rows per instance): a GroupNorm folded
+        # into this linear layer (ops.groupnorm_fold_linear) -- every instance's rows meet their own scaled weights
+        w_groups = kw.pop("w_groups", None)
+        weight, bias = layer.w, layer.bias
+        if w_groups is not None:
+            weight, bias = w_groups[0], None
+            kw.update(bias2=w_groups[1], bias2_rows=w_groups[2], w_group_rows=w_groups[2],
+                      w_group_stride=w_groups[0].shape[1] * w_groups[0].shape[2])
         st = None
         ws = r.sk_ws if m <= self.SPLITK_MAX_ROWS else None
         if ln_next is not None and layer.n_true in (256, 320, 512, 640) and layer.n == layer.n_true and not layer.geglu \
@@ -375,8 +387,8 @@ class SVDUNetHIP:
         temporal = (r.f, r.hw) if layer.mode == ops.A_TEMPORAL3 else None
         if layer.colsum is not None and "ln_stats" not in kw:
             raise RuntimeError("this contraction carries a folded LayerNorm: pass ln_stats")
-        ops.gemm(a, layer.w, out, m=m, n=layer.n, cin=layer.cin, mode=layer.mode, conv=conv, temporal=temporal,
-                 bias=layer.bias, geglu=layer.geglu, n_store=n_store, ldd=out.stride(0), lda=a.stride(0),
+        ops.gemm(a, weight, out, m=m, n=layer.n, cin=layer.cin, mode=layer.mode, conv=conv, temporal=temporal,
+                 bias=bias, geglu=layer.geglu, n_store=n_store, ldd=out.stride(0), lda=a.stride(0),
                  ln_colsum=layer.colsum, workspace=ws, **kw)
         if st is not None:
             # valid for exactly this tensor object in exactly this state (checked in _ln_stats): a view, a slice or an
@@ -466,10 +478,28 @@ class SVDUNetHIP:
         return self._gemm(r, att["out"], o, bias2=self._cross_vec(r, xvec), bias2_rows=r.f * r.hw, res1=resid,
                           r1scale=1.0, **epi)
 
+    # GroupNorm -> proj_in fold: the per-frame weight copies must stay small next to the pass they replace
+    GN_FOLD_MAX_WEIGHT_BYTES = 64 << 20
+
+    def _proj_in(self, r: _Run, p, x):
+        """``proj_in(norm(x))`` of a transformer.  The GroupNorm has no activation and feeds a linear layer, so where a
+        frame's rows are whole tiles (the 9,216- and 2,304-token levels) it is folded into per-frame weights
+        (``sp_groupnorm_fold_linear_f16``): one statistics pass over x instead of a statistics pass, an apply pass and the
+        normalised tensor's round trip through HBM.  Elsewhere: GroupNorm kernel + plain contraction."""
+        c, inst = p["c"], r.b * r.f
+        if self.fold_groupnorm and r.hw % 256 == 0 and inst * c * c * 2 <= self.GN_FOLD_MAX_WEIGHT_BYTES:
+            w_f = torch.empty((inst, c, c), dtype=torch.float16, device=self.device)
+            b_f = torch.empty((inst, c), dtype=torch.float32, device=self.device)
+            ops.groupnorm_fold_linear(x, p["norm"].g, p["norm"].b, p["pin"].w, p["pin"].bias, w_f, b_f, instances=inst,
+                                      rows=r.hw, c=c, groups=self.cfg.norm_groups, eps=p["norm"].eps, n=c, ws=r.gn_ws,
+                                      ldx=x.stride(0))
+            return self._gemm(r, p["pin"], x, ln_next=p["s_attn"]["qkv"], w_groups=(w_f, b_f, r.hw))
+        t = self._gn(r, p["norm"], x, temporal=False, silu=False)
+        return self._gemm(r, p["pin"], t, ln_next=p["s_attn"]["qkv"])
+
     def _run_transformer(self, r: _Run, p, x, out=None):
         c, a = p["c"], p["alpha"]
-        t = self._gn(r, p["norm"], x, temporal=False, silu=False)
-        hs = self._gemm(r, p["pin"], t, ln_next=p["s_attn"]["qkv"])
+        hs = self._proj_in(r, p, x)
         # --- spatial block
         hs1 = self._self_attn(r, p["s_attn"], p["s_x"], hs, temporal=False, ln_next=p["s_ff1"])
         g = self._gemm(r, p["s_ff1"], hs1, ln_stats=self._ln_stats(p["s_ff1"], hs1))

@@ -231,6 +231,12 @@ class PipelineStage:
         # optional observer, called on the last rank right after a sample's final step has been enqueued
         # (on that sample's stream) with the sample index - used by bench.py to time completions with events
         self.sample_done_hook: Callable[[int], None] | None = None
+        # edge-stage hooks (models/edge_stages.py::FrameEmitter; ref scripts/generate_video_demo.py:418 decodes on the last
+        # rank): `finished_latent_hook(idx, latent)` on the rank where sample idx's last step ran, on that sample's
+        # stream, right after the step was enqueued; `after_sample_hook(idx)` on EVERY rank once its share of sample idx
+        # (steps + hand-off) has been issued
+        self.finished_latent_hook: Callable[[int, torch.Tensor], None] | None = None
+        self.after_sample_hook: Callable[[int], None] | None = None
 
     # ------------------------------------------------------------------ logging
     def _log(self, message: str) -> None:
@@ -370,6 +376,8 @@ class PipelineStage:
                         finished.append(latents[j])
                         if self.sample_done_hook is not None:
                             self.sample_done_hook(group[j])
+                        if self.finished_latent_hook is not None:
+                            self.finished_latent_hook(group[j], latents[j])
                     else:
                         self._send_latent(latents[j])
                 if last:
@@ -379,6 +387,9 @@ class PipelineStage:
                 with torch.cuda.stream(self._streams[0]):
                     for _ in range(following):
                         self._link.post_recv()
+            if self.after_sample_hook is not None:
+                for idx in group:
+                    self.after_sample_hook(idx)
             self._log(f"samples {group[0]}..{group[-1]} issued on {len(group)} streams")
         return finished or None
 
@@ -483,6 +494,9 @@ class PipelineStage:
                         if self.sample_done_hook is not None:
                             with on(j):
                                 self.sample_done_hook(vid[j])
+                        if self.finished_latent_hook is not None:
+                            with on(j):
+                                self.finished_latent_hook(vid[j], finished[vid[j]])
                     continue
                 incoming = [j for j in lanes if ring_sample(r, g0 + j, s + 1, n) < num_samples]
                 got = exchange([(j, cur[j]) for j in live], incoming)
@@ -538,12 +552,18 @@ class PipelineStage:
             self._log(f"{label}final rank completed")
             if self.sample_done_hook is not None and sample_idx is not None:
                 self.sample_done_hook(sample_idx)
+            if self.finished_latent_hook is not None and sample_idx is not None:
+                self.finished_latent_hook(sample_idx, latent)
+            if self.after_sample_hook is not None and sample_idx is not None:
+                self.after_sample_hook(sample_idx)
             return latent
 
         self._send_latent(latent)
         if (self._link is not None and self._link.post_after_send and cfg.rank > 0 and self._more_samples_expected
                 and self._link.posted == 0):
             self._link.post_recv()
+        if self.after_sample_hook is not None and sample_idx is not None:
+            self.after_sample_hook(sample_idx)
         return None
 
     def drain(self) -> None:
