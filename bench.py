@@ -932,7 +932,7 @@ def main():
         # The line carries that commit and the algorithmic bytes (every operand / output / residual element once,
         # measured from this run's launches) so that the over-fetch ratio can be read off directly.
         traffic, traffic_src, traffic_commit = None, None, None
-        for name in ("r03n_pmc_traffic.json", "r03k_pmc_traffic.json", "r03i_pmc_traffic.json", "r03f_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r04_pmc_traffic.json", "r03n_pmc_traffic.json", "r03k_pmc_traffic.json", "r03i_pmc_traffic.json", "r03f_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pj.get("micro_batch", 1) != mb:      # bytes per launch scale with the videos per UNet call
@@ -942,10 +942,26 @@ def main():
                 break
             except Exception:
                 continue
+        # The clock the chip holds inside these K loops (2.4 GHz nominal is what the 2.5 PFLOP/s peak assumes) comes from
+        # in-kernel stamps of the experiments build (tools/clock_in_kernel.py): a static record too.
+        clock = None
+        for name in ("r04_clock_in_kernel.json",):
+            try:
+                clock = json.load(open(os.path.join(ROOT, "profiles", name)))
+                break
+            except Exception:
+                continue
+        clk_ghz = clock["clock_ghz_in_kernel"] if clock else None
         out["roofline"] = {"bound": "mfma",
                            "kernel": "gemm_pp_kernel / gemm_ps_kernel / gemm_f16_kernel (implicit-GEMM conv/linear)",
                            "achieved": gf / gt / 1e12, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                            "frac": gf / gt / 1e12 / PEAK_FP16_TFLOPS, "traffic": traffic,
+                           "traffic_static": True,      # measured by separate --pmc passes on the commit below, not in this run
+                           "clock_ghz_in_kernel": clk_ghz, "clock_static": True,
+                           "clock_measured_at_commit": clock.get("commit") if clock else None,
+                           "clock_source": clock.get("source") if clock else None,
+                           "clock_adjusted_peak": PEAK_FP16_TFLOPS * clk_ghz / 2.4 if clk_ghz else None,
+                           "frac_of_clock_adjusted_peak": (gf / gt / 1e12) / (PEAK_FP16_TFLOPS * clk_ghz / 2.4) if clk_ghz else None,
                            "traffic_source": traffic_src, "traffic_measured_at_commit": traffic_commit,
                            "algorithmic_bytes_per_launch": gb / gn,
                            "traffic_over_algorithmic": (traffic / (gb / gn)) if traffic else None,

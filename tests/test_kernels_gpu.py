@@ -671,7 +671,7 @@ def test_attention_spatial_long(batch, seq, heads, amp):
     o, ws = _attn_long(ops, qkv.half().to(DEV), c, batch, seq, heads)
     check(o, _sdpa(qkv, c, batch, seq, heads), l2=3e-3, mx=2e-2)
     if seq >= 4096 and seq % 256 == 0:
-        flags = ws.cpu().view(batch * heads, seq // 256)
+        flags = ws.cpu()[:batch * heads * (seq // 256)].view(batch * heads, seq // 256)     # (+ one word: flagged waves)
         assert set(flags.unique().tolist()) <= {0, 1}
         if amp == 1.0:        # unit-variance rows stay within 16 of their warm-up maximum; keys were planted in (0, 0) only
             assert int(flags[1:].sum()) == 0

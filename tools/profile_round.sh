@@ -3,6 +3,7 @@
 #   gpurun_out/<tag>_b_serial_stats.csv / _c_2streams_stats.csv : rocprofv3 --kernel-trace --stats of one / two micro-batches
 #                                                                   of two videos (25 / 50 UNet forwards at batch 2)
 #   gpurun_out/<tag>_a_pmc.txt + <tag>_pmc_traffic.json          : the three --pmc passes folded per kernel
+#   gpurun_out/<tag>_clock_in_kernel.json                         : shader clock held inside the K loops (experiments build stamps)
 #   gpurun_out/<tag>_bench.json                                   : the default bench line (per_template FLOPs)
 #   gpurun_out/<tag>_per_template.txt                             : fraction of peak per kernel template
 set -eu
@@ -22,6 +23,8 @@ bash tools/pmc_forward.sh gpurun_out/${TAG}_pmc
 python3 tools/pmc_forward_summary.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmc_traffic.json $COMMIT > gpurun_out/${TAG}_a_pmc.txt
 rm -rf "gpurun_out/${TAG}_pmc/fetch" "gpurun_out/${TAG}_pmc/write" "gpurun_out/${TAG}_pmc/mfma"
 echo pmc done
+python3 tools/clock_in_kernel.py gpurun_out/${TAG}_clock_in_kernel.json "$COMMIT" > gpurun_out/${TAG}_clock_in_kernel.txt 2>&1
+echo clock done
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 python3 tools/per_template_summary.py gpurun_out/${TAG}_b_serial_stats.csv gpurun_out/${TAG}_bench.json 25 > gpurun_out/${TAG}_per_template.txt
 cat gpurun_out/${TAG}_per_template.txt
