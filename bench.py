@@ -200,6 +200,67 @@ def usable_cores():
     return cores
 
 
+def ring_selftest(rank, n, device):
+    """The ring's hand-off with small payloads, exactly as pipeline._run_many_ring issues it: un-batched isend to rank+1
+    and irecv from rank-1 on a side stream, even ranks sending first and odd ranks receiving first (N = 2: both directions
+    share one communicator), twice (the first round creates the pair communicators).  True on every rank iff every rank
+    received its neighbour's payload both times."""
+    cuda = device.type == "cuda"
+    ok = torch.ones(1, device=device)
+    try:
+        side = torch.cuda.Stream(device=device) if cuda else None
+        for rnd in range(2):
+            out_t = torch.full((1024,), float(100 * rnd + rank), device=device)
+            in_t = torch.full((1024,), -1.0, device=device)
+            if cuda:
+                torch.cuda.synchronize(device)
+            with (torch.cuda.stream(side) if cuda else _Null()):
+                ops = [("s", out_t), ("r", in_t)] if rank % 2 == 0 else [("r", in_t), ("s", out_t)]
+                works = [dist.isend(t, dst=(rank + 1) % n) if k == "s" else dist.irecv(t, src=(rank - 1) % n) for k, t in ops]
+                for w in works:
+                    w.wait()
+            if cuda:
+                side.synchronize()
+                torch.cuda.synchronize(device)
+            if float(in_t[0]) != float(100 * rnd + (rank - 1) % n) or float(in_t[-1]) != float(in_t[0]):
+                ok.zero_()
+    except Exception as exc:  # noqa: BLE001
+        print(f"[rank {rank}] ring self-test failed ({exc!r}); using the chain schedule", file=sys.stderr, flush=True)
+        ok.zero_()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return bool(ok.item() > 0)
+
+
+def choose_in_flight(steps, n, ring, total_steps, args):
+    """(videos per UNet call, streams per GPU) with the smallest predicted time of the job.  More in flight raises a busy
+    stage's rate and lengthens the chain's fill and drain (ring: leaves the last group of batches emptier).  The four
+    per-forward times are a STATIC table (ms per video and UNet forward on one MI355X at 14 frames fp16, round 3,
+    tools/batch_vs_streams.py; their ORDER is what matters and holds at 25 frames too)."""
+    MS = {(1, 1): 52.3, (1, 2): 49.4, (2, 1): 49.8, (2, 2): 47.5}
+
+    def predicted(b, c):
+        per_stage = total_steps / n
+        if not ring or n == 1:
+            return (steps / (b * c) + n - 1) * b * c * per_stage * MS[(b, c)]
+        nbatch = -(-(steps // b) // n)                  # batches of N samples
+        full, rest = divmod(nbatch, c)                  # groups of c interleaved batches, then `rest` lanes
+        t = full * n * per_stage * b * c * MS[(b, c)]
+        if rest:
+            t += n * per_stage * b * rest * MS[(b, rest)]
+        return t
+
+    cands = [(b_, c_) for (b_, c_) in MS if steps % b_ == 0
+             and (args.micro_batch is None or args.micro_batch == b_) and (args.concurrent is None or args.concurrent == c_)]
+    if cands:
+        mb, conc = min(cands, key=lambda bc: predicted(*bc))
+        how = "static table of four per-forward times measured in round 3 (tools/batch_vs_streams.py), smallest predicted job time"
+    else:       # explicit values outside the table
+        mb = args.micro_batch if args.micro_batch is not None else 1
+        conc = max(1, args.concurrent if args.concurrent is not None else 2)
+        how = "given on the command line"
+    return mb, conc, how, {f"{b_}x{c_}": v for (b_, c_), v in MS.items()}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,11 +282,13 @@ def parse():
                     help="N>1: keep the extra step of the balanced split on the first ranks for every video "
                          "(default: rotate it with the video index so no stage is a permanent bottleneck)")
     ap.add_argument("--ring", action="store_true",
-                    help="N>1: ring schedule (video i starts on rank i mod N and visits every rank once: no pipeline "
-                         "fill/drain inside the timed region) instead of the reference's chain of stages (rank 0 feeds, "
-                         "last rank finishes).  Experimental: its grouped RCCL exchange has only run over Gloo so far; "
-                         "a self-test runs first and every rank falls back to the chain if it fails")
-    ap.add_argument("--no-ring", action="store_true", help="(default now; kept for older command lines)")
+                    help="(default at N > 1 since round 4; kept for older command lines)  Ring schedule: video i starts on "
+                         "rank i mod N and visits every rank once, so no pipeline fill / drain sits inside the timed region.  "
+                         "Same transport primitives as the chain (un-batched isend to rank+1 / irecv from rank-1); a "
+                         "self-test of exactly those calls runs first and every rank falls back to the chain if it fails")
+    ap.add_argument("--chain", "--no-ring", dest="chain", action="store_true",
+                    help="N>1: the reference's chain of stages (rank 0 feeds, last rank finishes; the extra step of the "
+                         "balanced split rotates with the video index unless --no-rotate) instead of the ring")
     ap.add_argument("--watchdog", type=float, default=120.0,
                     help="seconds without progress after which a rank prints where it is and exits with status 3")
     ap.add_argument("--long-attention", action="store_true", help="(default since round 4; kept for older command lines)")
@@ -642,28 +705,8 @@ def main():
     # both sides drain it) stays near 5-10 %; ~20-40 s at every N
     steps = args.steps if args.steps is not None else (16 if n == 1 else 32 * n)
     # How many videos a GPU keeps in flight: `mb` videos travel together as ONE pipeline sample of shape (mb,4,F,H,W)
-    # (north_star: "micro-batched pipeline"), `conc` samples are interleaved on separate HIP streams.  More in flight
-    # raises the rate of a busy stage but lengthens the chain's fill and drain, which matters when the job is short for
-    # its N: pick the pair with the smallest predicted time (groups + N - 1) x group time.  The four per-forward times
-    # are a STATIC table (ms per video and UNet forward measured on one MI355X at 14 frames fp16 in round 3:
-    # tools/batch_vs_streams.py; their ORDER is what matters and holds at 25 frames too); the line says so
-    # (`in_flight_choice`).  `steps` and `value` keep counting VIDEOS.
-    MS = {(1, 1): 52.3, (1, 2): 49.4, (2, 1): 49.8, (2, 2): 47.5}
-    cands = [(b_, c_) for (b_, c_) in MS if steps % b_ == 0
-             and (args.micro_batch is None or args.micro_batch == b_) and (args.concurrent is None or args.concurrent == c_)]
-    if cands:
-        mb, conc = min(cands, key=lambda bc: (steps / (bc[0] * bc[1]) + n - 1) * bc[0] * bc[1] * MS[bc])
-    else:       # explicit values outside the table
-        mb = args.micro_batch if args.micro_batch is not None else 1
-        conc = max(1, args.concurrent if args.concurrent is not None else 2)
-    if mb < 1 or steps % mb:
-        raise SystemExit(f"bench.py: --steps {steps} videos is not a whole number of micro-batches of {mb}")
-    warmup_requested = args.warmup
-    warmup = args.warmup if args.warmup is not None else (2 * mb * conc if n == 1 else max(2 * n, 2 * mb * conc))
-    n_samples = steps // mb
-    warm_samples = -(-warmup // mb)
-    warmup = warm_samples * mb              # whole micro-batches: --warmup 5 with micro-batches of two runs 6
-
+    # (north_star: "micro-batched pipeline"), `conc` samples are interleaved on separate HIP streams: chosen below, once
+    # the schedule is known (choose_in_flight).  `steps` and `value` keep counting VIDEOS.
     if shared:
         # rehearsal only (PIPELINE_BACKEND=gloo on a one-GPU box): ranks share the cards that exist; RCCL refuses this
         local_rank %= max(1, torch.cuda.device_count())
@@ -699,11 +742,28 @@ def main():
         if not shared and len({(r["device"], r["uuid"]) for r in ranks_seen}) != n:
             raise SystemExit(f"bench.py: {n} ranks but they do not sit on {n} distinct devices: {ranks_seen}")
 
+    # ---- schedule: ring by default at N > 1 (no fill / drain inside the timed region), after a self-test of its hand-off
+    T = args.total_steps
+    ring = n > 1 and not args.chain
+    selftest = "not requested" if n > 1 else "single GPU"
+    if ring:
+        dog.beat("ring self-test")
+        ring = ring_selftest(rank, n, device)
+        selftest = "passed" if ring else "FAILED on some rank (chain schedule used)"
+    mb, conc, how_chosen, ms_table = choose_in_flight(steps, n, ring, T, args)
+    if mb < 1 or steps % mb:
+        raise SystemExit(f"bench.py: --steps {steps} videos is not a whole number of micro-batches of {mb}")
+    warmup_requested = args.warmup
+    warmup = args.warmup if args.warmup is not None else (2 * mb * conc if n == 1 else max(2 * n, 2 * mb * conc))
+    n_samples = steps // mb
+    warm_samples = -(-warmup // mb)
+    warmup = warm_samples * mb              # whole micro-batches: --warmup 5 with micro-batches of two runs 6
+
+
     from vdpp_amd.models.unet_spec import UNetConfig, forward_flops
     from vdpp_amd.hip import ops
     from vdpp_amd.models.svd_unet import StableVideoUNet
 
-    T = args.total_steps
     lat_dtype = torch.float16
     if rehearse:
         from vdpp_amd.models import DummyUNet
@@ -722,35 +782,12 @@ def main():
     spec = LatentSpec(shape=shape, dtype=lat_dtype, device=device)
     import logging
     quiet = logging.getLogger("bench.quiet"); quiet.setLevel(logging.ERROR)
-    ring = n > 1 and args.ring and not args.no_ring
-    selftest = "not requested"
-    if ring:
-        dog.beat("ring self-test")
-        # self-test of the grouped neighbour exchange the ring schedule relies on (also warms the communicator);
-        # if any rank cannot do it, every rank falls back to the chain schedule
-        ok = torch.ones(1, device=device)
-        try:
-            probe_out = torch.full((4,), float(rank), device=device)
-            probe_in = torch.empty(4, device=device)
-            works = dist.batch_isend_irecv([dist.P2POp(dist.isend, probe_out, (rank + 1) % n),
-                                            dist.P2POp(dist.irecv, probe_in, (rank - 1) % n)])
-            for wk in works:
-                wk.wait()
-            sync()
-            if float(probe_in[0]) != float((rank - 1) % n):
-                ok.zero_()
-        except Exception as exc:  # noqa: BLE001
-            print(f"[rank {rank}] ring self-test failed ({exc!r}); using the chain schedule", file=sys.stderr)
-            ok.zero_()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        ring = bool(ok.item() > 0)
-        selftest = "passed" if ring else "FAILED on some rank (chain schedule used)"
     rotating = n > 1 and not ring and not args.no_rotate
     stage = PipelineStage(model, PipelineConfig(total_steps=T, world_size=n, rank=rank, timesteps=list(range(T)),
                                                 latent_spec=spec, balanced=True, concurrent_samples=conc,
                                                 rotate=rotating, ring=ring),
                           logger=quiet)
-    probe = {"ran": False, "why": "single rank" if n == 1 else "ring schedule (grouped exchanges)"}
+    probe = {"ran": False, "why": "single rank" if n == 1 else "ring schedule (its own self-test ran: " + selftest + ")"}
     if n > 1 and not ring:
         dog.beat("p2p probe")
         probe = p2p_probe(rank, n, device)
@@ -850,10 +887,8 @@ def main():
                        "path): " if rehearse else "") + "steady-state videos/sec (whole node), SVD 14f x 25step",
             "value": value, "unit": "videos/s", "n_gpus": n, "steps": steps, "warmup": warmup,
             "warmup_requested": warmup_requested,     # --warmup is rounded up to whole micro-batches
-            "in_flight_choice": {"micro_batch": mb, "streams": conc, "how": "static table of four per-forward times "
-                                 "measured in round 3 (tools/batch_vs_streams.py), smallest predicted job time"
-                                 if cands else "given on the command line", "table_ms_per_video_forward":
-                                 {f"{b_}x{c_}": v for (b_, c_), v in MS.items()}},
+            "in_flight_choice": {"micro_batch": mb, "streams": conc, "how": how_chosen, "table_ms_per_video_forward": ms_table},
+            "ring_selftest": selftest,
             "transport_per_rank": transports, "p2p_probe": probe,
             "world_size_seen_by_process_group": dist.get_world_size() if n > 1 else 1,
             "backend": dist.get_backend() if n > 1 else "none", "ranks": ranks_seen, "rccl_env": rccl_env,

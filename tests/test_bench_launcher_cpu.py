@@ -126,16 +126,22 @@ def test_visible_gpus_honours_visible_devices_lists(monkeypatch, tmp_path):
     assert bench.visible_gpus() == 2
 
 
-def test_eight_rank_job_through_the_launcher_on_cpu_tensors():
-    """`bench.py --gpus 8` end to end -- launcher, torchrun, process group, p2p probe, rotating chain [4,3,3,3,3,3,3,3],
-    watchdog, all_gather_object, steady-state arithmetic, ONE JSON line -- with the simulator's DummyUNet on CPU tensors
-    over Gloo (--rehearse-cpu: a box without 8 GPUs cannot run the real thing, and at most 6 processes may share the one
-    GPU of the test box).  The line must say what the process group saw and must label itself a rehearsal."""
+import pytest
+
+
+@pytest.mark.parametrize("schedule", ["ring", "chain"])
+def test_eight_rank_job_through_the_launcher_on_cpu_tensors(schedule):
+    """`bench.py --gpus 8` end to end -- launcher, torchrun, process group, ring self-test / p2p probe, the ring schedule
+    (the default at N > 1) and the rotating chain [4,3,3,3,3,3,3,3] (--chain), watchdog, all_gather_object, steady-state
+    arithmetic, ONE JSON line -- with the simulator's DummyUNet on CPU tensors over Gloo (--rehearse-cpu: a box without 8
+    GPUs cannot run the real thing, and at most 6 processes may share the one GPU of the test box).  The line must say what
+    the process group saw and must label itself a rehearsal.  20 videos with 5 of warm-up: the driver's own flags."""
     e = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VDPP_SHARE_GPU", "PIPELINE_BACKEND"):
         e.pop(k, None)
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "16", "--warmup", "8", "--rehearse-cpu",
-                        "--frames", "4", "--height", "16", "--width", "16"], cwd=ROOT, env=e, capture_output=True,
+    extra = ["--chain"] if schedule == "chain" else []
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5", "--rehearse-cpu",
+                        "--frames", "4", "--height", "16", "--width", "16"] + extra, cwd=ROOT, env=e, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -143,12 +149,20 @@ def test_eight_rank_job_through_the_launcher_on_cpu_tensors():
     d = json.loads(lines[0])
     assert d["metric"].startswith("REHEARSAL, NOT A MEASUREMENT") and d["rehearsal"] == "cpu"
     assert d["n_gpus"] == 8 and d["world_size_seen_by_process_group"] == 8 and d["backend"] == "gloo"
-    assert d["config"]["stage_steps"] == [4, 3, 3, 3, 3, 3, 3, 3] and d["config"]["stage_steps_rotate_with_video_index"]
-    assert d["steps"] == 16 and d["warmup"] == 8 and d["warmup_requested"] == 8
+    assert d["config"]["stage_steps"] == [4, 3, 3, 3, 3, 3, 3, 3]
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["warmup_requested"] == 5
     assert len(d["ranks"]) == 8 and sorted(x["rank"] for x in d["ranks"]) == list(range(8))
     assert len(d["transport_per_rank"]) == 8
-    assert d["p2p_probe"]["ran"] and d["p2p_probe"]["data_ok"] and not d["p2p_probe"]["serialised"]
-    assert len(d["p2p_probe"]["arrived_s"]) == 8 and d["p2p_probe"]["arrived_s"][1] >= 0.3   # rank 1 waited for the late sender
+    if schedule == "ring":
+        assert d["config"]["schedule"].startswith("ring") and d["ring_selftest"] == "passed"
+        assert not d["config"]["stage_steps_rotate_with_video_index"] and not d["p2p_probe"]["ran"]
+        assert (d["micro_batch"], d["streams_per_gpu"]) == (1, 2)      # 3 batches of 8: two interleaved, then one
+        assert all(t["kind"].startswith("ring") for t in d["transport_per_rank"])
+    else:
+        assert d["config"]["schedule"].startswith("chain") and d["config"]["stage_steps_rotate_with_video_index"]
+        assert d["p2p_probe"]["ran"] and d["p2p_probe"]["data_ok"] and not d["p2p_probe"]["serialised"]
+        assert len(d["p2p_probe"]["arrived_s"]) == 8 and d["p2p_probe"]["arrived_s"][1] >= 0.3   # rank 1 waited for the late sender
+        assert (d["micro_batch"], d["streams_per_gpu"]) == (1, 1)      # a short job for 8 ranks: shortest fill and drain
     assert d["value"] > 0 and d["steady_state_videos_per_s_last_rank"] > 0 and d["first_video_latency_s"] > 0
     assert abs(d["ms_per_step"] * d["value"] - 1e3) < 1e-6 * 1e3
     for k in range(8):

@@ -423,7 +423,7 @@ def test_side_stream_link_with_emulated_stream_ordered_p2p(monkeypatch, conc, ro
 @pytest.mark.parametrize("world,num_samples,conc", [(3, 7, 2), (2, 4, 1), (4, 6, 2)])
 def test_ring_schedule_with_emulated_stream_ordered_p2p(monkeypatch, world, num_samples, conc):
     """The ring schedule (PipelineConfig.ring) with its GPU transport: `world` ranks emulated by threads of ONE process
-    on one GPU; `batch_isend_irecv` is replaced by stream-ordered mailbox copies per directed link (what a grouped RCCL
+    on one GPU; `isend` / `irecv` are replaced by stream-ordered mailbox copies per directed link (what an RCCL
     send/recv provides).  Exercises the event choreography of `_run_many_ring` (compute lanes -> side stream ->
     compute lanes), the interleaved lanes and the final collection, and checks every sample == the 1-rank result."""
     import collections
@@ -436,28 +436,24 @@ def test_ring_schedule_with_emulated_stream_ordered_p2p(monkeypatch, world, num_
 
     links = collections.defaultdict(queue.Queue)          # (src, dst) -> FIFO of (tensor, ready_event)
     me = threading.local()
-    FakeOp = collections.namedtuple("FakeOp", "op tensor peer")
 
-    def fake_batch(ops):
-        works = []
-        for op in ops:                                     # sends first: they never block
-            if op.op is pl.dist.isend:
-                ev = torch.cuda.Event()
-                staged = op.tensor.clone()                 # on the issuing stream, ordered behind its wait_event
-                ev.record(torch.cuda.current_stream())
-                links[(me.rank, op.peer)].put((staged, ev))
-                works.append(_FakeWork())
-        for op in ops:
-            if op.op is pl.dist.irecv:
-                def complete(op=op):
-                    staged, ev = links[(op.peer, me.rank)].get(timeout=120)
-                    torch.cuda.current_stream().wait_event(ev)
-                    op.tensor.copy_(staged)
-                works.append(_FakeWork(complete))
-        return works
+    def fake_isend(tensor, dst, tag=0):
+        ev = torch.cuda.Event()
+        staged = tensor.clone()                            # on the issuing stream, ordered behind its wait_event
+        ev.record(torch.cuda.current_stream())
+        links[(me.rank, dst)].put((staged, ev))
+        return _FakeWork()
 
-    monkeypatch.setattr(pl.dist, "P2POp", FakeOp)
-    monkeypatch.setattr(pl.dist, "batch_isend_irecv", fake_batch)
+    def fake_irecv(buf, src, tag=0):
+        def complete():                                    # runs inside work.wait() on the issuing (side) stream
+            staged, ev = links[(src, me.rank)].get(timeout=120)
+            torch.cuda.current_stream().wait_event(ev)
+            buf.copy_(staged)
+        return _FakeWork(complete)
+
+    monkeypatch.setattr(pl.dist, "isend", fake_isend)
+    monkeypatch.setattr(pl.dist, "irecv", fake_irecv)
+    monkeypatch.setattr(pl.dist, "is_initialized", lambda: False)     # (no process group: plain stream-ordered mailboxes)
 
     cfg, sd, ref, hip = _build(seed=31)
     steps = 7

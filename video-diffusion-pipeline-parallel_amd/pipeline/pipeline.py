@@ -396,15 +396,19 @@ class PipelineStage:
     def _run_many_ring(self, num_samples: int, input_supplier) -> list[torch.Tensor] | None:
         """Ring schedule (extension).  Samples are taken in batches of N = world_size; in slot ``s`` of a batch this
         rank runs stage ``s`` (the ``s``-th range of the balanced split) of the sample whose home rank is
-        ``(rank - s) mod N``, then hands it to rank+1 and receives its slot ``s+1`` sample from rank-1, both in ONE
-        ``batch_isend_irecv`` (a grouped RCCL call: safe on a ring, also for N = 2 where both neighbours are the same
-        peer).  In every slot all ranks run the same stage index, so slots line up and nobody waits for a pipeline to
-        fill or drain.  ``concurrent_samples`` batches are interleaved on separate HIP streams: their kernels share
-        the GPU, but the exchange is bulk-synchronous per slot (ONE grouped exchange for all lanes, ordered behind
-        every lane's last step of the slot), so a lane does not overlap its own hand-off with its own compute; the
-        1-2 MB hand-off is microseconds on xGMI against >= 150 ms of stage compute.  Finished latents are
-        collected on the last rank at the end (same return contract as the chain: list on the last rank, ``None``
-        elsewhere).  Every rank needs the ``input_supplier`` (it produces the inputs of its home samples)."""
+        ``(rank - s) mod N``, then hands it to rank+1 and receives its slot ``s+1`` sample from rank-1.  In every slot
+        all ranks run the same stage index, so slots line up and nobody waits for a pipeline to fill or drain.
+        Transport (round 4): the SAME primitives as the chain of stages -- un-batched ``isend`` to rank+1 and ``irecv``
+        from rank-1 (torch gives every rank pair its own communicator and stream), on a side stream behind events of
+        the compute lanes -- so the ring needs nothing of RCCL that the chain does not; even ranks send first and odd
+        ranks receive first, which is what keeps N = 2 (both neighbours are the same peer: one communicator, one
+        stream) free of the send-waits-for-send deadlock and is harmless elsewhere.  ``concurrent_samples`` batches are
+        interleaved on separate HIP streams: their kernels share the GPU, but the exchange is bulk-synchronous per slot
+        (one exchange for all lanes, ordered behind every lane's last step of the slot); the 1-2 MB hand-off is
+        microseconds on xGMI against >= 150 ms of stage compute.  Finished latents travel on to the last rank over the
+        same neighbour links at the end (a sample that finished on rank f makes N-1-f hops), so the return contract is
+        the chain's: list on the last rank, ``None`` elsewhere.  Every rank needs the ``input_supplier`` (it produces
+        the inputs of its home samples)."""
 
         cfg = self.config
         n, r = cfg.world_size, cfg.rank
@@ -430,12 +434,23 @@ class PipelineStage:
         def on(j):  # compute stream of interleave lane j (no-op context on CPU)
             return torch.cuda.stream(self._streams[j]) if cuda else _NullCtx()
 
+        def neighbour_p2p(sends, recvs):
+            """isend every tensor of `sends` to rank+1, irecv every tensor of `recvs` from rank-1 (un-batched: the chain's
+            primitives); even ranks send first, odd ranks receive first.  Returns the works in issue order."""
+            works = []
+            first, second = (("s", sends), ("r", recvs)) if r % 2 == 0 else (("r", recvs), ("s", sends))
+            for kind, tensors in (first, second):
+                for t in tensors:
+                    works.append(dist.isend(t, dst=nxt_rank, tag=cfg.send_tag) if kind == "s"
+                                 else dist.irecv(t, src=prv_rank, tag=cfg.send_tag))
+            return works
+
         def exchange(outgoing, incoming_lanes):
             """outgoing: [(lane, tensor)] to rank+1; incoming_lanes: lanes that receive from rank-1.
             Returns {lane: received tensor}, each lane's stream already ordered behind the transfer."""
             if not outgoing and not incoming_lanes:
                 return {}
-            ops, got = [], {}
+            got = {}
             if cuda:
                 side = self._ring_stream
                 for j, t in outgoing:
@@ -446,12 +461,10 @@ class PipelineStage:
                 with torch.cuda.stream(side):
                     for j in incoming_lanes:
                         got[j] = cfg.latent_spec.empty()
-                    for j, t in outgoing:
-                        ops.append(dist.P2POp(dist.isend, t, nxt_rank))
-                    for j in incoming_lanes:
-                        ops.append(dist.P2POp(dist.irecv, got[j], prv_rank))
-                    for w in dist.batch_isend_irecv(ops):
-                        w.wait()                        # stream-level: the side stream waits, not the host
+                    if incoming_lanes and _gloo_moves_gpu_tensor(got[incoming_lanes[0]]):
+                        side.synchronize()              # Gloo writes from the host: the buffers' memory must be free by now
+                    for w in neighbour_p2p([t for _, t in outgoing], [got[j] for j in incoming_lanes]):
+                        w.wait()                        # RCCL: stream-level (the side stream waits, not the host)
                     done = torch.cuda.Event(); done.record(side)
                 for j in incoming_lanes:
                     self._streams[j].wait_event(done)
@@ -460,11 +473,7 @@ class PipelineStage:
             else:
                 for j in incoming_lanes:
                     got[j] = cfg.latent_spec.empty()
-                for j, t in outgoing:
-                    ops.append(dist.P2POp(dist.isend, t, nxt_rank))
-                for j in incoming_lanes:
-                    ops.append(dist.P2POp(dist.irecv, got[j], prv_rank))
-                for w in dist.batch_isend_irecv(ops):
+                for w in neighbour_p2p([t for _, t in outgoing], [got[j] for j in incoming_lanes]):
                     w.wait()
             return got
 
@@ -508,26 +517,36 @@ class PipelineStage:
             for t in finished.values():
                 t.record_stream(main)
 
-        # ---- collect on the last rank (sample i finished on rank (i mod N) - 1)
+        # ---- collect on the last rank: sample i finished on rank f = ring_finish_rank(i) and makes N-1-f hops over the
+        # neighbour links r -> r+1 (never the wrap-around link: rank N-1 only receives, rank 0 only sends).  In round d every
+        # rank forwards what it holds and receives what rank-1 holds, in sample order (both sides know the lists).
         last = n - 1
-        ops, out = [], {}
-        if r == last:
-            for i in range(num_samples):
-                src = ring_finish_rank(i, n)
-                if src == last:
-                    out[i] = finished[i]
-                else:
-                    out[i] = cfg.latent_spec.empty()
-                    ops.append(dist.P2POp(dist.irecv, out[i], src))
-        else:
-            for i in sorted(finished):
-                ops.append(dist.P2POp(dist.isend, finished[i], last))
-        if ops and cuda and dist.is_initialized() and dist.get_backend() == "gloo":
-            torch.cuda.synchronize(dev)              # (see _gloo_moves_gpu_tensor)
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        return [out[i] for i in range(num_samples)] if r == last else None
+        holder = {i: ring_finish_rank(i, n) for i in range(num_samples)}
+        have: dict[int, torch.Tensor] = dict(finished)
+        host_staged = cuda and dist.is_initialized() and dist.get_backend() == "gloo"     # (see _gloo_moves_gpu_tensor)
+        for _ in range(n - 1):
+            moving = sorted(i for i, hr in holder.items() if hr != last)
+            if not moving:
+                break
+            out_ids = [i for i in moving if holder[i] == r]
+            in_ids = [i for i in moving if holder[i] == r - 1]
+            bufs = {i: cfg.latent_spec.empty() for i in in_ids}
+            if host_staged:
+                torch.cuda.synchronize(dev)          # what is sent has been produced, what is received into is free
+            works = []
+            order = (("s", out_ids), ("r", in_ids)) if r % 2 == 0 else (("r", in_ids), ("s", out_ids))
+            for kind, ids in order:
+                for i in ids:
+                    works.append(dist.isend(have[i], dst=r + 1, tag=cfg.send_tag) if kind == "s"
+                                 else dist.irecv(bufs[i], src=r - 1, tag=cfg.send_tag))
+            for w in works:
+                w.wait()                             # RCCL: orders the current stream behind the transfer
+            for i in out_ids:
+                del have[i]                          # (the process group keeps a sent tensor alive until its send has run)
+            have.update(bufs)
+            for i in moving:
+                holder[i] += 1
+        return [have[i] for i in range(num_samples)] if r == last else None
 
     def _process_single_latent(
         self, input_latent: torch.Tensor | None, sample_idx: int | None
@@ -576,6 +595,9 @@ class PipelineStage:
     def transport(self) -> dict:
         """What moves this stage's latents (bench.py prints it per rank): the side-stream link with its counters, or
         the reference's blocking send/recv."""
+        if self.config.ring and self.config.world_size > 1:
+            return {"kind": "ring: un-batched isend to rank+1 / irecv from rank-1 on a side stream (Gloo: on the host), "
+                            "even ranks send first, odd ranks receive first"}
         if self._link is None:
             return {"kind": "blocking send/recv on the compute stream"}
         return dict(self._link.stats, kind="side-stream link", host_ordered=self._link.host_ordered,
