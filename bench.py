@@ -1022,6 +1022,31 @@ def main():
                             "avg_launch_us": 1e6 * at / an}
         if "roofline_attention" not in out and "roofline_attention_short_rows" in out:
             out["roofline_attention"] = out.pop("roofline_attention_short_rows")
+    # ---- the reference benchmark's own order, one video per UNet call and one at a time (ref src/modes/benchmark.py:101
+    # batch_size=1), beside the headline so that rounds and configurations stay comparable: a short leg, never `value`
+    if rank == 0 and n == 1 and not rehearse and (mb, conc) != (1, 1):
+        with torch.no_grad():
+            torch.manual_seed(args.seed)
+            model.set_dummy_conditioning(1, args.frames, args.height, args.width, device, guidance_scale=args.guidance_scale)
+            shape1 = torch.Size((1, 4, args.frames, args.height, args.width))
+            stage1 = PipelineStage(model, PipelineConfig(total_steps=T, world_size=1, rank=0, timesteps=list(range(T)),
+                                                         latent_spec=LatentSpec(shape=shape1, dtype=torch.float16, device=device),
+                                                         balanced=True, concurrent_samples=1), logger=quiet)
+
+            def supplier1(i):
+                gen.manual_seed(args.seed + 5000 + i)
+                return torch.randn(shape1, generator=gen, device=device, dtype=torch.float16) * model.init_noise_sigma
+
+            stage1.run_many(1, input_supplier=supplier1)
+            sync()
+            t1 = time.perf_counter()
+            stage1.run_many(3, input_supplier=supplier1)
+            sync()
+            dt1 = (time.perf_counter() - t1) / 3
+        out["reference_order_batch1_one_at_a_time"] = {
+            "videos_per_s": 1.0 / dt1, "ms_per_unet_forward": 1e3 * dt1 / (T * passes), "videos": 3,
+            "note": "micro-batch 1, one video in flight (the reference benchmark's batch_size=1 loop); the headline runs "
+                    f"micro-batches of {mb} on {conc} streams"}
     # ---- what the last stage would add per video if it also decoded (ref scripts/generate_video_demo.py:
     # 154-195: decode_latents, decode_chunk_size 14).  Outside the headline metric: the benchmark's videos are latents.
     if rank == 0 and not args.no_decode:

@@ -311,3 +311,43 @@ def test_image_to_video_flow_through_the_edge_stages():
     torch.cuda.synchronize()
     assert video.shape == (1, 3, frames, 8 * h, 8 * w) and video.dtype == torch.float32 and torch.isfinite(video).all()
     assert rel_l2(video.cpu(), ref_decode(out.float().cpu(), dec_ref, frames)) <= 2e-2
+
+
+def test_edge_engines_load_from_a_local_checkpoint_directory(tmp_path):
+    """ref scripts/generate_video_demo.py:248-262 loads the CLIP image encoder and the VAE by model id; with this backend a
+    LOCAL directory in the hub layout (image_encoder/, vae/: config.json + *.safetensors) gives the three engines, which
+    must compute what engines built from the same state_dicts compute; a model NAME is refused (no network)."""
+    import json
+
+    from safetensors.torch import save_file
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from vdpp_amd.models.clip_hip import CLIPVisionHIP, CLIPVisionSpec
+    from vdpp_amd.models.edge_stages import load_edge_engines
+    from vdpp_amd.models.vae_hip import (ImageEncoderHIP, TemporalDecoderHIP, VAEDecoderConfig, random_encoder_state_dict,
+                                         random_state_dict)
+
+    ccfg = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=56,
+                            patch_size=14, projection_dim=64)
+    torch.manual_seed(5)
+    csd = {k: v.half().contiguous() for k, v in CLIPVisionModelWithProjection(ccfg).state_dict().items()}
+    vcfg = VAEDecoderConfig.tiny(64)
+    dsd, esd = random_state_dict(vcfg, seed=7), random_encoder_state_dict(vcfg, seed=8)
+    (tmp_path / "image_encoder").mkdir(); (tmp_path / "vae").mkdir()
+    save_file(csd, str(tmp_path / "image_encoder" / "model.fp16.safetensors"))
+    save_file({k: torch.zeros_like(v) for k, v in csd.items()}, str(tmp_path / "image_encoder" / "model.safetensors"))  # ignored
+    (tmp_path / "image_encoder" / "config.json").write_text(json.dumps(ccfg.to_dict()))
+    save_file({**{"decoder." + k: v.contiguous() for k, v in dsd.items()}, **{k: v.contiguous() for k, v in esd.items()}},
+              str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
+    (tmp_path / "vae" / "config.json").write_text(json.dumps({"block_out_channels": list(vcfg.block_out_channels),
+                                                               "latent_channels": 4, "layers_per_block": 2,
+                                                               "scaling_factor": vcfg.scaling_factor}))
+    clip, enc, dec = load_edge_engines(str(tmp_path), DEV)
+    g = torch.Generator().manual_seed(3)
+    px = torch.randn(1, 3, 56, 56, generator=g).half().to(DEV)
+    img = torch.randn(1, 3, 64, 64, generator=g).clamp(-1, 1).half().to(DEV)
+    lat = torch.randn(1, 4, 2, 8, 8, generator=g).half().to(DEV)
+    assert torch.equal(clip(px), CLIPVisionHIP(CLIPVisionSpec.from_config(ccfg), csd, DEV)(px))
+    assert torch.equal(enc.encode_image_latents(img, 2), ImageEncoderHIP(vcfg, esd, DEV).encode_image_latents(img, 2))
+    assert torch.equal(dec.decode_latents(lat, 2), TemporalDecoderHIP(vcfg, dsd, DEV).decode_latents(lat, 2))
+    with pytest.raises(ValueError, match="LOCAL checkpoint directory"):
+        load_edge_engines("stabilityai/stable-video-diffusion-img2vid-xt", DEV)

@@ -14,6 +14,60 @@ from .clip_hip import CLIPVisionHIP
 from .vae_hip import ImageEncoderHIP, TemporalDecoderHIP
 
 
+def _read_local_checkpoint(model_dir: str, subfolder: str) -> tuple[dict, dict]:
+    """``(state_dict, config)`` of ``<model_dir>/<subfolder>`` in the hub layout (``*.safetensors`` -- the ``.fp16.`` variant
+    when both are shipped -- and ``config.json``).  Local directories only: there is no network to fetch a model name."""
+    import json
+    import os
+
+    sub = os.path.join(model_dir, subfolder)
+    if not os.path.isdir(sub):
+        raise ValueError(f"'{model_dir}' holds no '{subfolder}' directory: pass a LOCAL checkpoint directory in the hub "
+                         f"layout (a model name cannot be fetched: no network access)")
+    from safetensors.torch import load_file
+
+    files = sorted(n for n in os.listdir(sub) if n.endswith(".safetensors"))
+    fp16_files = [n for n in files if ".fp16." in n]
+    sd = {}
+    for name in (fp16_files or files):
+        sd.update(load_file(os.path.join(sub, name)))
+    if not sd:
+        raise ValueError(f"no *.safetensors weights under '{sub}'")
+    cfg = {}
+    cfg_path = os.path.join(sub, "config.json")
+    if os.path.exists(cfg_path):
+        with open(cfg_path) as fh:
+            cfg = json.load(fh)
+    return sd, cfg
+
+
+def load_edge_engines(model_dir: str, device="cuda"):
+    """``(clip, vae_encoder, vae_decoder)`` from a local Stable Video Diffusion checkpoint directory, as the reference's
+    demo loads them by id (``CLIPVisionModelWithProjection.from_pretrained(.., subfolder="image_encoder")``,
+    ``AutoencoderKLTemporalDecoder.from_pretrained(.., subfolder="vae")``: ref ``scripts/generate_video_demo.py:248-262``)."""
+    from .clip_hip import CLIPVisionSpec
+    from .vae_hip import VAEDecoderConfig
+
+    csd, ccfg = _read_local_checkpoint(model_dir, "image_encoder")
+    d = CLIPVisionSpec()
+    spec = CLIPVisionSpec(ccfg.get("hidden_size", d.hidden_size), ccfg.get("intermediate_size", d.intermediate_size),
+                          ccfg.get("num_hidden_layers", d.num_hidden_layers), ccfg.get("num_attention_heads", d.num_attention_heads),
+                          ccfg.get("image_size", d.image_size), ccfg.get("patch_size", d.patch_size),
+                          ccfg.get("projection_dim", d.projection_dim), ccfg.get("layer_norm_eps", d.layer_norm_eps),
+                          ccfg.get("hidden_act", d.hidden_act))
+    clip = CLIPVisionHIP(spec, csd, device)
+    vsd, vcfg = _read_local_checkpoint(model_dir, "vae")
+    v = VAEDecoderConfig()
+    cfg = VAEDecoderConfig(latent_channels=vcfg.get("latent_channels", v.latent_channels),
+                           out_channels=vcfg.get("out_channels", v.out_channels),
+                           block_out_channels=tuple(vcfg.get("block_out_channels", v.block_out_channels)),
+                           layers_per_block=vcfg.get("layers_per_block", v.layers_per_block),
+                           scaling_factor=vcfg.get("scaling_factor", v.scaling_factor))
+    enc = ImageEncoderHIP(cfg, {k: t for k, t in vsd.items() if k.startswith(("encoder.", "quant_conv."))}, device)
+    dec = TemporalDecoderHIP(cfg, {k[len("decoder."):]: t for k, t in vsd.items() if k.startswith("decoder.")}, device)
+    return clip, enc, dec
+
+
 def encode_image(pixel_values: torch.Tensor, image_tensor: torch.Tensor, image_encoder: CLIPVisionHIP,
                  vae_encoder: ImageEncoderHIP, num_frames: int, noise: torch.Tensor | None = None,
                  noise_aug_strength: float = 0.0) -> tuple[torch.Tensor, torch.Tensor]:
