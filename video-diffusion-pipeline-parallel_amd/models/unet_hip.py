@@ -487,7 +487,8 @@ class SVDUNetHIP:
         (``sp_groupnorm_fold_linear_f16``): one statistics pass over x instead of a statistics pass, an apply pass and the
         normalised tensor's round trip through HBM.  Elsewhere: GroupNorm kernel + plain contraction."""
         c, inst = p["c"], r.b * r.f
-        if self.fold_groupnorm and r.hw % 256 == 0 and inst * c * c * 2 <= self.GN_FOLD_MAX_WEIGHT_BYTES:
+        if (self.fold_groupnorm and r.hw % 256 == 0 and (c % 256 == 0 or c % 320 == 0)          # whole ping-pong tiles
+                and inst * c * c * 2 <= self.GN_FOLD_MAX_WEIGHT_BYTES):
             w_f = torch.empty((inst, c, c), dtype=torch.float16, device=self.device)
             b_f = torch.empty((inst, c), dtype=torch.float32, device=self.device)
             ops.groupnorm_fold_linear(x, p["norm"].g, p["norm"].b, p["pin"].w, p["pin"].bias, w_f, b_f, instances=inst,
