@@ -302,6 +302,8 @@ def parse():
                     help="skip the edge-stage timings (temporal-VAE decode, CLIP / VAE image encode; reported beside the "
                          "headline metric, never inside it)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-batch1-leg", action="store_true",
+                    help="skip the short one-video-at-a-time leg (`reference_order_batch1_one_at_a_time`; profiling runs)")
     ap.add_argument("--emit-frames", action="store_true",
                     help="also time the pipeline WITH its last edge stage (secondary figure `frames_out`, never `value`): every "
                          "finished latent is decoded to frames by the temporal VAE on a stream of its own beside the UNet "
@@ -1024,7 +1026,7 @@ def main():
             out["roofline_attention"] = out.pop("roofline_attention_short_rows")
     # ---- the reference benchmark's own order, one video per UNet call and one at a time (ref src/modes/benchmark.py:101
     # batch_size=1), beside the headline so that rounds and configurations stay comparable: a short leg, never `value`
-    if rank == 0 and n == 1 and not rehearse and (mb, conc) != (1, 1):
+    if rank == 0 and n == 1 and not rehearse and not args.no_batch1_leg and (mb, conc) != (1, 1):
         with torch.no_grad():
             torch.manual_seed(args.seed)
             model.set_dummy_conditioning(1, args.frames, args.height, args.width, device, guidance_scale=args.guidance_scale)

@@ -21,8 +21,19 @@ def short(n):
 rows = {short(r["Name"]): r for r in csv.DictReader(open(stats))}
 print(f"{'kernel instantiation':52s} {'launches/fwd':>12s} {'ms/fwd':>8s} {'TFLOP/fwd':>10s} {'TFLOP/s':>8s} {'of 2.5 PF':>9s}")
 tot_ms = tot_fl = 0.0
+# templates that run the same main kernel (e.g. "X" and "X + ln_part_finalize_kernel": the same gemm_pp instantiation with and
+# without the follow-up that folds two-tile row statistics) share that kernel's CSV row: fold them into one line
+merged = {}
 for t in bench["roofline"]["per_template"]:
     parts = [p.strip() for p in t["kernel"].split("+")]
+    m = merged.setdefault(parts[0], {"parts": [], "tflop": 0.0})
+    m["tflop"] += t["tflop"]
+    for p in parts:
+        if p not in m["parts"]:
+            m["parts"].append(p)
+for t in merged.values():
+    parts = t["parts"]
+    t["kernel"] = " + ".join(parts)
     ns = calls = 0.0
     for p in parts:
         r = rows.get(p)

@@ -10,11 +10,11 @@ set -eu
 TAG=${1:?usage: profile_round.sh <tag> <commit>}; COMMIT=${2:?usage: profile_round.sh <tag> <commit>}
 R=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is unset: run this on the GPU box (gpurun exports it)}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_ps -- python3 $R/bench.py --concurrent 1 --steps 2 --warmup 0 --no-cpu-baseline --no-roofline --no-decode > $R/gpurun_out/${TAG}_b_serial.json 2> $R/gpurun_out/${TAG}_b_serial.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_ps -- python3 $R/bench.py --concurrent 1 --steps 2 --warmup 0 --no-cpu-baseline --no-roofline --no-decode --no-batch1-leg > $R/gpurun_out/${TAG}_b_serial.json 2> $R/gpurun_out/${TAG}_b_serial.err
 cp $(find $R/gpurun_out/${TAG}_ps -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_b_serial_stats.csv
 rm -rf "$R/gpurun_out/${TAG}_ps"
 echo serial done
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_p2 -- python3 $R/bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-roofline --no-decode > $R/gpurun_out/${TAG}_c_2streams.json 2> $R/gpurun_out/${TAG}_c_2streams.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_p2 -- python3 $R/bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-roofline --no-decode --no-batch1-leg > $R/gpurun_out/${TAG}_c_2streams.json 2> $R/gpurun_out/${TAG}_c_2streams.err
 cp $(find $R/gpurun_out/${TAG}_p2 -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_c_2streams_stats.csv
 rm -rf "$R/gpurun_out/${TAG}_p2"
 echo two-streams done
