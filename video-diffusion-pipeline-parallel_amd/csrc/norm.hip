@@ -341,36 +341,55 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(const f16 *__restrict__ x
   }
 }
 
-// GroupNorm folded into the linear layer behind it (sp_groupnorm_fold_linear_f16): one wave per (instance, output row n)
-// scales the weight row by gamma[c] * rstd[instance][group(c)], rounds it to fp16 and takes the row's bias from the ROUNDED
-// values (so that a constant offset of a group cancels exactly in the contraction).  instances * n * c halves written.
+// GroupNorm folded into the linear layer behind it (sp_groupnorm_fold_linear_f16): a block builds the instance's per-channel
+// tables once in LDS (scale = gamma * rstd[group], mean[group], beta), then each of its waves walks output rows: the weight row
+// times the scale, rounded to fp16, and the row's bias from the ROUNDED values (so that a constant offset of a group cancels
+// exactly in the contraction).  instances * n * c halves written; no division and no global statistics read in the row loop.
+constexpr int GN_FOLD_ROWS = 32;               // output rows per block (8 per wave)
 __global__ __launch_bounds__(256) void gn_fold_linear_kernel(const float *__restrict__ stats, const f16 *__restrict__ w,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
                                                              const float *__restrict__ bias, f16 *__restrict__ w_out,
                                                              float *__restrict__ bias_out, int n, int c, int groups) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *t_scale = (float *)smem, *t_mean = t_scale + c, *t_beta = t_mean + c;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int inst = blockIdx.x;
-  const int row = blockIdx.y * 4 + wave;
-  if (row >= n) return;
-  const int oc = c >> 3, cpg = c / groups;
+  const int cpg = c / groups;
   const float *st = stats + (int64_t)inst * groups * 2;
-  const f16 *wr = w + (int64_t)row * c;
-  f16 *wo = w_out + ((int64_t)inst * n + row) * c;
-  float acc = 0.f;
-  for (int o = lane; o < oc; o += 64) {
-    const f16x8 v = *(const f16x8 *)(wr + o * 8);
-    f16x8 q;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int ch = o * 8 + e, g = ch / cpg;
-      const float wv = (float)v[e];
-      q[e] = (f16)(wv * (gamma ? gamma[ch] : 1.f) * st[g * 2 + 1]);
-      acc += (beta ? beta[ch] : 0.f) * wv - st[g * 2] * (float)q[e];
-    }
-    *(f16x8 *)(wo + o * 8) = q;
+  for (int ch = tid; ch < c; ch += 256) {
+    const int g = ch / cpg;
+    t_scale[ch] = (gamma ? gamma[ch] : 1.f) * st[g * 2 + 1];
+    t_mean[ch] = st[g * 2];
+    t_beta[ch] = beta ? beta[ch] : 0.f;
   }
-  acc = wave_sum(acc);
-  if (lane == 0) bias_out[(int64_t)inst * n + row] = acc + (bias ? bias[row] : 0.f);
+  __syncthreads();
+  const int oc = c >> 3;
+  const int row0 = blockIdx.y * GN_FOLD_ROWS;
+  for (int rr = wave; rr < GN_FOLD_ROWS; rr += 4) {
+    const int row = row0 + rr;
+    if (row >= n) break;
+    const f16 *wr = w + (int64_t)row * c;
+    f16 *wo = w_out + ((int64_t)inst * n + row) * c;
+    float acc = 0.f;
+    for (int o = lane; o < oc; o += 64) {
+      const f16x8 v = *(const f16x8 *)(wr + o * 8);
+      const f32x4 s0 = *(const f32x4 *)(t_scale + o * 8), s1 = *(const f32x4 *)(t_scale + o * 8 + 4);
+      const f32x4 m0 = *(const f32x4 *)(t_mean + o * 8), m1 = *(const f32x4 *)(t_mean + o * 8 + 4);
+      const f32x4 b0 = *(const f32x4 *)(t_beta + o * 8), b1 = *(const f32x4 *)(t_beta + o * 8 + 4);
+      f16x8 q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float w0 = (float)v[e], w1 = (float)v[e + 4];
+        q[e] = (f16)(w0 * s0[e]);
+        q[e + 4] = (f16)(w1 * s1[e]);
+        acc += b0[e] * w0 - m0[e] * (float)q[e];
+        acc += b1[e] * w1 - m1[e] * (float)q[e + 4];
+      }
+      *(f16x8 *)(wo + o * 8) = q;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) bias_out[(int64_t)inst * n + row] = acc + (bias ? bias[row] : 0.f);
+  }
 }
 
 // rows per statistics block: about 1024 blocks in all, >= 16 row-iterations per thread, at most 512 splits per instance
@@ -672,8 +691,9 @@ extern "C" int sp_groupnorm_fold_linear_f16(const void *x, int64_t ldx, const fl
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(instances), dim3(1024), 0, s, (const f16 *)x, (const float *)ws, stats, rows, c,
                      groups, splits, eps, ldx);
   SP_CHECK_LAUNCH("sp_groupnorm_fold_linear_f16(finalize)");
-  hipLaunchKernelGGL(gn_fold_linear_kernel, dim3(instances, (n + 3) / 4), dim3(256), 0, s, (const float *)stats,
-                     (const f16 *)w, gamma, beta, bias, (f16 *)w_out, bias_out, n, c, groups);
+  hipLaunchKernelGGL(gn_fold_linear_kernel, dim3(instances, (n + GN_FOLD_ROWS - 1) / GN_FOLD_ROWS), dim3(256),
+                     (size_t)3 * c * sizeof(float), s, (const float *)stats, (const f16 *)w, gamma, beta, bias, (f16 *)w_out,
+                     bias_out, n, c, groups);
   SP_CHECK_LAUNCH("sp_groupnorm_fold_linear_f16(fold)");
   return SP_OK;
 }
