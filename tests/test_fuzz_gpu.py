@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
-@pytest.mark.parametrize("route,bm", [(0, 0), (2, 256), (2, 192), (2, 128), (1, 0), (3, 256), (3, 192), (3, 128), (4, 0)])
+@pytest.mark.parametrize("route,bm", [(0, 0), (2, 256), (2, 192), (2, 128), (1, 0), (3, 256), (3, 192), (3, 128), (3, -192), (4, 0)])
 def test_gemm_fuzz(route, bm):
     """route: sp_gemm_set_route (0 automatic, 1 small tiles, 2 ping-pong, 3 persistent-stream, 4 split-K); route 3 draws
     long-K, many-row linear shapes more often so that workgroups walk several tiles, route 4 few-row shapes with
@@ -22,7 +22,8 @@ def test_gemm_fuzz(route, bm):
     from vdpp_amd.hip import ops
     seed = 1000 + bm + route
     rng, g = random.Random(seed), torch.Generator().manual_seed(seed)
-    with ops.gemm_route(route, bm=bm):
+    # bm -192: the 256 x 192 persistent tiles (widths that are multiples of 192); other shapes take the automatic choice
+    with (ops.gemm_route(3, bm=256, bn=192) if bm == -192 else ops.gemm_route(route, bm=bm)):
         worst = max(fuzz_gemm.one(rng, g, stream_shapes=route == 3, splitk=route == 4) for _ in range(30))
     assert worst <= 3e-3
 

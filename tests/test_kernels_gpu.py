@@ -117,7 +117,10 @@ def test_gemm_large_tile_geglu_conv_temporal(force_large_tiles):
                                             # 128 x 320 tiles (4 x 2 waves): every N = 320 k of the two outer levels
                                             (128, 50001, 960, 320, False), (128, 36000, 320, 1280, False),
                                             (128, 129024 // 2, 320, 320, False), (128, 33001, 640, 640, False),
-                                            (128, 32256, 1920, 640, False)])
+                                            (128, 32256, 1920, 640, False),
+                                            # 256 x 192 tiles (4 x 2 waves): the fused Q/K/V widths 960 and 1,920 (bm -192 = "bn 192")
+                                            (-192, 50001, 960, 320, False), (-192, 32256, 1920, 640, False),
+                                            (-192, 40000, 192, 1280, False)])
 def test_gemm_persistent_stream_many_tiles(bm, m, n, k, geglu):
     """gemm_ps.hip with several tiles per workgroup (grid 256, up to 6 tiles each): the LDS-DMA stream crosses tile
     boundaries, stores of tile i are in flight behind the loads of tile i+1.  bias + bias2 (one row per batch item),
@@ -142,8 +145,10 @@ def test_gemm_persistent_stream_many_tiles(bm, m, n, k, geglu):
                   r2scale=-0.25, oscale=2.0)
         y = 2.0 * (y + b2) + 0.5 * res - 0.25 * res2
         wdev = w.half().to(DEV)
-    with ops.gemm_route(3, bm=bm):
+    with (ops.gemm_route(3, bm=256, bn=192) if bm == -192 else ops.gemm_route(3, bm=bm)):
         ops.gemm(a.half().to(DEV), wdev, out[1:m + 1], **kw)
+        if bm == -192:
+            assert ops.load().sp_gemm_last_kernel().decode().startswith("gemm_ps_kernel<256, 192"), ops.load().sp_gemm_last_kernel()
     torch.cuda.synchronize()
     assert torch.all(out[0] == 7.0) and torch.all(out[m + 1] == 7.0), "guard rows written"
     check(out[1:m + 1], y)

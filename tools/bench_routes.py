@@ -9,7 +9,7 @@ import torch
 import vdpp_amd  # noqa
 from vdpp_amd.hip import ops
 
-ARMS = [("auto", (0, 0, 0)), ("pp", (2, 0, 0)), ("ps256", (3, 256, 0)), ("ps192", (3, 192, 0)), ("ps128x320", (3, 128, 320))]
+ARMS = [("auto", (0, 0, 0)), ("pp", (2, 0, 0)), ("ps256", (3, 256, 0)), ("ps192", (3, 192, 0)), ("ps128x320", (3, 128, 320)), ("ps256x192", (3, 256, 192))]
 SPLITK_ARMS = [("small", (1, 0, 0)), ("128x64", (1, 128, 0)), ("split-K", (4, 0, 0)), ("auto+ws", (0, 0, 0))]   # m <= 6144
 
 

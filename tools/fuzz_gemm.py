@@ -31,7 +31,7 @@ def one(rng, g, stream_shapes=False, splitk=False):
     if splitk and rng.random() < 0.8:
         n, cin = rng.choice([256, 512, 1280]), rng.choice([128, 320, 640])
     if stream_shapes and rng.random() < 0.7:          # what gemm_ps.hip takes: linear, K >= 256, N % 256 or % 320
-        mode, n, cin = 0, rng.choice([256, 320, 512, 640, 960, 1280, 2560]), rng.choice([320, 640, 1280])
+        mode, n, cin = 0, rng.choice([192, 256, 320, 512, 640, 960, 1280, 1920, 2560]), rng.choice([320, 640, 1280])
     geglu = mode == 0 and n % 128 == 0 and rng.random() < 0.3
     kw = {}
     if mode == 0:

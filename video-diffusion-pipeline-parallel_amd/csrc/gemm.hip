@@ -542,13 +542,21 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
 
   // ---- persistent-stream tiles (gemm_ps.hip): linear contractions with several tiles per CU, where launch gap,
   // index setup, first-operand latency and the LDS-staged epilogue of a one-tile workgroup are a large share
-  if ((route == 0 || route == 3) && (ok256 || ok320)) {
+  if ((route == 0 || route == 3) && (ok256 || ok320 || d->n % 192 == 0)) {
     int bm = 0, bn = 0;
     double best = 0.0;
-    const int cand[3][2] = {{256, 256}, {192, 256}, {128, 320}};
-    for (int c = 0; c < 3; ++c) {
+    const int cand[4][2] = {{256, 256}, {192, 256}, {128, 320}, {256, 192}};
+    for (int c = 0; c < 4; ++c) {
       const int cbm = cand[c][0], cbn = cand[c][1];
-      if ((cbn == 256 && !ok256) || (cbn == 320 && !ok320)) continue;
+      if ((cbn == 256 && !ok256) || (cbn == 320 && !ok320) || (cbn == 192 && (d->n % 192 || d->geglu))) continue;
+      // 256 x 192 tiles (round 4): widths that are multiples of 192 but not of 256 -- the fused Q/K/V projections of the two
+      // outer levels, 960 and 1,920 columns -- which otherwise run one tile per workgroup on the ping-pong kernel: measured
+      // 266.6 -> 212.6 us at 258,048 x 960 x 320 and 181.2 -> 172.2 at 64,512 x 1,920 x 640 (profiles/r04_ps256x192.txt)
+      if (cbn == 192 && ok256 && !(route == 3 && g_route_bn == 192)) continue;
+#ifdef SP_GEMM_EXPERIMENTS
+      if (cbn == 192 && (a.dbg & 1024) && route == 0) continue;       // in-situ A/B: the choice before this kernel existed
+#endif
+      if (route == 3 && g_route_bn == 192 && cbn != 192) continue;
       if (route == 3 && ((g_route_bm && g_route_bm != cbm) || (g_route_bn && g_route_bn != cbn))) continue;
       // 128 x 320 tiles: built and verified (round 3), never chosen automatically -- 1.4x the LDS-DMA pieces per FLOP of
       // a 256-row tile; measured 0-25 % slower than the ping-pong kernel's 256 x 320 tiles on every N = 320 k shape of
@@ -656,7 +664,7 @@ extern "C" int sp_gemm_set_route(int route, int bm, int bn) {
   SP_REQUIRE(route >= 0 && route <= 4,
              "sp_gemm_set_route: route %d (0 auto, 1 small tiles, 2 ping-pong, 3 persistent-stream, 4 split-K)", route);
   SP_REQUIRE(bm == 0 || bm == 128 || bm == 192 || bm == 256, "sp_gemm_set_route: bm %d", bm);
-  SP_REQUIRE(bn == 0 || bn == 256 || bn == 320, "sp_gemm_set_route: bn %d", bn);
+  SP_REQUIRE(bn == 0 || bn == 256 || bn == 320 || bn == 192, "sp_gemm_set_route: bn %d", bn);
   g_route = route; g_route_bm = bm; g_route_bn = bn;
   return SP_OK;
 }

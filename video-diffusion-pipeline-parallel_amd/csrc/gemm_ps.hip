@@ -503,8 +503,8 @@ bool ps_supported(const GemmArgs &a, int bm, int bn) {
   // sub-tiles of two row sub-tiles per wave: 80 accumulator registers).  A 256 x 320 tile in that arrangement holds 160
   // accumulator registers and its residual prefetch does not fit the register file without spills (measured 0.6x the
   // ping-pong kernel in round 2).
-  if (!((bn == 256 && (bm == 256 || bm == 192)) || (bn == 320 && bm == 128))) return false;
-  if (bn == 320 && a.geglu) return false;         // (value, gate) pairs of an odd number of sub-tile pairs
+  if (!((bn == 256 && (bm == 256 || bm == 192)) || (bn == 320 && bm == 128) || (bn == 192 && bm == 256))) return false;
+  if ((bn == 320 || bn == 192) && a.geglu) return false;         // (value, gate) pairs of an odd number of sub-tile pairs
   if (a.n % bn) return false;
   if (a.mode != SP_A_LINEAR) return false;        // the tile loop streams plain rows (nn.Linear / 1x1 convolution)
   if (a.k < 8 * SBK) return false;
@@ -525,6 +525,9 @@ bool ps_supported(const GemmArgs &a, int bm, int bn) {
 template <int VAR>
 int launch_ps_v(GemmArgs &a, int bm, int bn, hipStream_t s) {
   if (bn == 320) return launch_ps_t<128, 320, 4, 2, false, VAR>(a, s);
+  // 256 x 192 (4 x 2 waves of 64 x 96: 96 accumulator registers): widths that are multiples of 192 but not of 256 -- the
+  // fused Q/K/V projections of the two outer levels (960 = 5 x 192, 1,920 = 10 x 192)
+  if (bn == 192) return launch_ps_t<256, 192, 4, 2, false, VAR>(a, s);
   if (a.geglu) return bm == 192 ? launch_ps_t<192, 256, 2, 4, true, VAR>(a, s) : launch_ps_t<256, 256, 2, 4, true, VAR>(a, s);
   return bm == 192 ? launch_ps_t<192, 256, 2, 4, false, VAR>(a, s) : launch_ps_t<256, 256, 2, 4, false, VAR>(a, s);
 }
