@@ -3,7 +3,8 @@
 them in flight on two HIP streams): the arms alternate for ROUNDS rounds, best and median ms per video and forward.
 usage: ab_forward.py [--lib exp] [--rounds 5] [--steps 6] ARM ARM ...
 ARM = comma-separated settings: env:NAME=VALUE (process environment, e.g. env:SP_GEMM_DBG=256 with --lib exp) or
-      unet:ATTR=0|1 (attribute of the SVDUNetHIP engine, e.g. unet:fold_groupnorm=0, unet:long_attention=0); "base" = nothing."""
+      unet:ATTR=0|1 (attribute of the SVDUNetHIP engine, e.g. unet:fold_groupnorm=0, unet:long_attention=0) or
+      route:R=BM (sp_gemm_set_route(R, BM, 0) for the whole forward, e.g. route:2=0 = ping-pong kernels only); "base" = nothing."""
 import argparse, os, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -36,6 +37,7 @@ def apply(arm):
         setattr(model.unet, k, v)
     for name in [n for n in os.environ if n.startswith("SP_GEMM_")]:
         del os.environ[name]
+    hip.load().sp_gemm_set_route(0, 0, 0)
     if arm == "base":
         return
     for item in arm.split(","):
@@ -43,6 +45,8 @@ def apply(arm):
         name, val = rest.split("=", 1)
         if kind == "env":
             os.environ[name] = val
+        elif kind == "route":
+            hip.load().sp_gemm_set_route(int(name), int(val), 0)
         elif kind == "unet":
             defaults.setdefault(name, getattr(model.unet, name))
             setattr(model.unet, name, bool(int(val)))
