@@ -234,9 +234,9 @@ def ring_selftest(rank, n, device):
 def choose_in_flight(steps, n, ring, total_steps, args):
     """(videos per UNet call, streams per GPU) with the smallest predicted time of the job.  More in flight raises a busy
     stage's rate and lengthens the chain's fill and drain (ring: leaves the last group of batches emptier).  The four
-    per-forward times are a STATIC table (ms per video and UNet forward on one MI355X at 14 frames fp16, round 3,
-    tools/batch_vs_streams.py; their ORDER is what matters and holds at 25 frames too)."""
-    MS = {(1, 1): 52.3, (1, 2): 49.4, (2, 1): 49.8, (2, 2): 47.5}
+    per-forward times are a STATIC table (ms per video and UNet forward on one MI355X at 14 frames fp16, round 4,
+    tools/batch_vs_streams.py -> profiles/r04_batch_vs_streams.txt; their ORDER is what matters and holds at 25 frames too)."""
+    MS = {(1, 1): 51.9, (1, 2): 48.6, (2, 1): 48.5, (2, 2): 46.8}
 
     def predicted(b, c):
         per_stage = total_steps / n
@@ -253,7 +253,7 @@ def choose_in_flight(steps, n, ring, total_steps, args):
              and (args.micro_batch is None or args.micro_batch == b_) and (args.concurrent is None or args.concurrent == c_)]
     if cands:
         mb, conc = min(cands, key=lambda bc: predicted(*bc))
-        how = "static table of four per-forward times measured in round 3 (tools/batch_vs_streams.py), smallest predicted job time"
+        how = "static table of four per-forward times measured in round 4 (tools/batch_vs_streams.py, profiles/r04_batch_vs_streams.txt), smallest predicted job time"
     else:       # explicit values outside the table
         mb = args.micro_batch if args.micro_batch is not None else 1
         conc = max(1, args.concurrent if args.concurrent is not None else 2)
