@@ -915,6 +915,8 @@ def main():
                                     "chain: rank 0 feeds, last rank finishes") if n > 1 else "single GPU",
                        "parallelism": f"step-pipeline pp{n}" if n > 1 else "single GPU (no pipeline split)"},
             "steady_state_videos_per_s_last_rank": steady, "first_video_latency_s": fill,
+            "first_video_latency_note": f"completion of the first pipeline sample = {mb} video(s) travelling together, with {conc} "
+                                        f"sample(s) sharing the GPU: longer than one video alone (--micro-batch 1 --concurrent 1)",
             "unet_forward_tflop_algorithmic": flops_all["total"] / 1e12,
             "unet_forward_tflop_executed": flops_exec / 1e12,
         }
