@@ -549,15 +549,13 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
     for (int c = 0; c < 4; ++c) {
       const int cbm = cand[c][0], cbn = cand[c][1];
       if ((cbn == 256 && !ok256) || (cbn == 320 && !ok320) || (cbn == 192 && (d->n % 192 || d->geglu))) continue;
-      // 256 x 192 tiles (round 4): widths that are multiples of 192 but not of 256 -- the fused Q/K/V projections of the two
-      // outer levels, 960 and 1,920 columns -- which otherwise run one tile per workgroup on the ping-pong kernel: measured
-      // 266.6 -> 212.6 us at 258,048 x 960 x 320 and 181.2 -> 172.2 at 64,512 x 1,920 x 640 (profiles/r04_ps256x192.txt)
-      if (cbn == 192 && ok256 && !(route == 3 && g_route_bn == 192)) continue;
-#ifdef SP_GEMM_EXPERIMENTS
-      if (cbn == 192 && (a.dbg & 1024) && route == 0) continue;       // in-situ A/B: the choice before this kernel existed
-#endif
+      // 256 x 192 tiles (round 4; widths that are multiples of 192 but not of 256: the fused Q/K/V projections of the two
+      // outer levels): built and verified, never chosen automatically.  With the SAME operand buffers launch after launch
+      // (Infinity-Cache-resident) they beat the ping-pong kernel by 25 % at 258,048 x 960 x 320 (266.6 -> 212.6 us); with
+      // operands that a launch does not find in the cache (tools/bench_routes.py COLD=6), as inside a forward, they lose
+      // 6 % there and 14 % at 64,512 x 1,920 x 640, and the in-situ A/B reads -0.2 % / 0 (profiles/r04_ps256x192.txt)
+      if (cbn == 192 && !(route == 3 && g_route_bn == 192)) continue;
       if (route == 3 && g_route_bn == 192 && cbn != 192) continue;
-      if (route == 3 && ((g_route_bm && g_route_bm != cbm) || (g_route_bn && g_route_bn != cbn))) continue;
       // 128 x 320 tiles: built and verified (round 3), never chosen automatically -- 1.4x the LDS-DMA pieces per FLOP of
       // a 256-row tile; measured 0-25 % slower than the ping-pong kernel's 256 x 320 tiles on every N = 320 k shape of
       // the two outer levels
