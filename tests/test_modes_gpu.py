@@ -162,7 +162,7 @@ def test_frames_out_of_the_pipelined_run_equal_decode_of_the_plain_loop(tmp_path
         assert base["frames"][i].shape == (1, 3, 3, 64, 128) and torch.isfinite(want).all()
         assert torch.equal(base["frames"][i], want), f"sample {i}: emitted frames differ from decode_latents"
     for world, extra, where in ((2, (), lambda i, n: i % n), (3, (), lambda i, n: i % n), (3, ("--no-spread",), lambda i, n: n - 1),
-                                (2, ("--schedule", "ring"), None)):
+                                (2, ("--schedule", "ring"), None), (3, ("--schedule", "ring", "--concurrent", "1"), None)):
         ranks = run(world, *extra)
         seen = {}
         for r, rec in enumerate(ranks):
