@@ -78,6 +78,13 @@ class Watchdog:
             if idle > self.limit:
                 print(f"[rank {self.rank}] WATCHDOG: no progress for {idle:.0f} s at '{self.where}'; exiting with status 3",
                       file=sys.stderr, flush=True)
+                status = os.environ.get("VDPP_BENCH_STATUS")       # read by this rank's supervisor (supervise_rank)
+                if status:
+                    try:
+                        with open(status, "w") as fh:
+                            fh.write(self.where)
+                    except OSError:
+                        pass
                 os._exit(3)
 
 
@@ -177,6 +184,30 @@ class _HostEvent:
         return 1e3 * (other.t - self.t)
 
 
+def pmc_dominant_template():
+    """MFMA-busy / wait fractions of the contraction template with the most time, from the committed PMC pass of two
+    forwards (separate --pmc runs: tools/pmc_forward.sh -> profiles/*_two_forwards_pmc_per_kernel.txt); static, like
+    `traffic`.  busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CU cycles), wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES."""
+    for name in ("r05_a_two_forwards_pmc_per_kernel.txt", "r04_a_two_forwards_pmc_per_kernel.txt"):
+        try:
+            rows = [ln.split() for ln in open(os.path.join(ROOT, "profiles", name)) if ln.startswith("gemm_")]
+        except OSError:
+            continue
+        best = None
+        for r in rows:
+            try:
+                busy, wait = float(r[-2]), float(r[-1])
+                ms = float(r[-6])
+            except (ValueError, IndexError):
+                continue
+            if best is None or ms > best[0]:
+                best = (ms, " ".join(r[:-7]), busy, wait)
+        if best:
+            return {"kernel": best[1], "mfma_busy": best[2], "wait": best[3], "ms_in_two_forwards": best[0],
+                    "source": f"profiles/{name}", "static": True}
+    return None
+
+
 def usable_cores():
     """Host cores this process may actually use: the affinity mask, cut by the cgroup CPU quota if there is one."""
     try:
@@ -231,12 +262,50 @@ def ring_selftest(rank, n, device):
     return bool(ok.item() > 0)
 
 
-def choose_in_flight(steps, n, ring, total_steps, args):
+def measure_in_flight_table(model, device, args, n, dog):
+    """ms per video and UNet forward for (videos per call, streams) in {1,2}^2, timed on THIS job's GPUs during start-up
+    (two rounds of one UNet step per stream after one warm round; ~3 s), max over ranks so that every rank chooses alike.
+    None if anything goes wrong (the static table decides then)."""
+    try:
+        table = {}
+        T = args.total_steps
+        for b in (1, 2):
+            torch.manual_seed(args.seed)
+            model.set_dummy_conditioning(b, args.frames, args.height, args.width, device, guidance_scale=args.guidance_scale)
+            lat = (torch.randn((b, 4, args.frames, args.height, args.width), device=device) * 10).half()
+            streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+            for c in (1, 2):
+                dog.beat(f"in-flight table {b}x{c}")
+                times = []
+                for rnd in range(3):
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    for st in streams[:c]:
+                        with torch.cuda.stream(st), torch.no_grad():
+                            model(lat, T // 2)
+                    torch.cuda.synchronize(device)
+                    times.append(time.perf_counter() - t0)
+                table[(b, c)] = 1e3 * min(times[1:]) / (b * c)
+        model.unet.release_stream_state()
+        keys = sorted(table)
+        t = torch.tensor([table[k] for k in keys], dtype=torch.float64, device=device)
+        if n > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return {k: float(v) for k, v in zip(keys, t.tolist())}
+    except Exception as exc:  # noqa: BLE001
+        print(f"bench.py: in-flight table not measured ({exc!r}); using the static one", file=sys.stderr, flush=True)
+        return None
+
+
+def choose_in_flight(steps, n, ring, total_steps, args, measured=None):
     """(videos per UNet call, streams per GPU) with the smallest predicted time of the job.  More in flight raises a busy
     stage's rate and lengthens the chain's fill and drain (ring: leaves the last group of batches emptier).  The four
     per-forward times are a STATIC table (ms per video and UNet forward on one MI355X at 14 frames fp16, round 4,
     tools/batch_vs_streams.py -> profiles/r04_batch_vs_streams.txt; their ORDER is what matters and holds at 25 frames too)."""
     MS = {(1, 1): 51.9, (1, 2): 48.6, (2, 1): 48.5, (2, 2): 46.8}
+    static = measured is None
+    if measured is not None:
+        MS = dict(measured)
 
     def predicted(b, c):
         per_stage = total_steps / n
@@ -253,7 +322,8 @@ def choose_in_flight(steps, n, ring, total_steps, args):
              and (args.micro_batch is None or args.micro_batch == b_) and (args.concurrent is None or args.concurrent == c_)]
     if cands:
         mb, conc = min(cands, key=lambda bc: predicted(*bc))
-        how = "static table of four per-forward times measured in round 4 (tools/batch_vs_streams.py, profiles/r04_batch_vs_streams.txt), smallest predicted job time"
+        how = ("static table of four per-forward times measured in round 4 (tools/batch_vs_streams.py, profiles/r04_batch_vs_streams.txt)"
+               if static else "four per-forward times measured on this job's GPUs at start-up (max over ranks)") + ", smallest predicted job time"
     else:       # explicit values outside the table
         mb = args.micro_batch if args.micro_batch is not None else 1
         conc = max(1, args.concurrent if args.concurrent is not None else 2)
@@ -289,6 +359,9 @@ def parse():
     ap.add_argument("--chain", "--no-ring", dest="chain", action="store_true",
                     help="N>1: the reference's chain of stages (rank 0 feeds, last rank finishes; the extra step of the "
                          "balanced split rotates with the video index unless --no-rotate) instead of the ring")
+    ap.add_argument("--no-fallback", action="store_true",
+                    help="N>1: run this rank in the launched process itself instead of under its supervisor (no second attempt "
+                         "on the chain / the blocking transport when the first one stalls)")
     ap.add_argument("--watchdog", type=float, default=120.0,
                     help="seconds without progress after which a rank prints where it is and exits with status 3")
     ap.add_argument("--long-attention", action="store_true", help="(default since round 4; kept for older command lines)")
@@ -630,6 +703,154 @@ def p2p_env(env):
                                     "HSA_ENABLE_IPC_MODE_LEGACY")}
 
 
+# ---- the first RCCL run must not end without a number ------------------------------------------------------------------
+# Every schedule / transport of the multi-rank path has only ever run over Gloo (1-GPU leases).  If the default (ring) stalls
+# on RCCL, the watchdog ends every rank with status 3 -- and the one scaling measurement the driver takes would yield nothing.
+# So with N > 1 every RANK process is a small supervisor (standard library only: it never touches the GPU) that runs the
+# actual benchmark rank as a FRESH child process (never an exec), and when the attempt fails on any rank all supervisors
+# start the next rung of the ladder together, with a fresh process group on a fresh port:
+#     ring  ->  chain on the side-stream link  ->  chain with the reference's blocking send/recv (ref src/pipeline/pipeline.py:
+#     75-84,134-157; `--chain`, `VDPP_ASYNC_COMM=0`)
+# The supervisors agree through files in a directory under the temp dir keyed by their common parent (the torchrun agent).
+# The driver launches `python -m torch.distributed.run ... bench.py --gpus N`, so this has to live in the ranks; the
+# launcher-less `python bench.py --gpus N` reaches the same code through its own torchrun child (launch_ranks).
+LADDER = (
+    {"key": "ring", "schedule": "ring", "transport": "un-batched isend/irecv on a side stream", "flags": [], "env": {}},
+    {"key": "chain", "schedule": "chain", "transport": "side-stream link (isend / pre-posted irecv)", "flags": ["--chain"], "env": {}},
+    {"key": "blocking", "schedule": "chain", "transport": "blocking send/recv on the compute stream (the reference's)",
+     "flags": ["--chain"], "env": {"VDPP_ASYNC_COMM": "0"}},
+)
+RC_USAGE = 2          # a worker that refuses its arguments: no other rung would accept them either
+
+
+def _usage(msg):
+    """Refused arguments / environment: exit status RC_USAGE, which the supervisors do not answer with another attempt."""
+    print(msg, file=sys.stderr, flush=True)
+    sys.exit(RC_USAGE)
+
+
+def ladder_for(args, env):
+    if env.get("VDPP_ASYNC_COMM") == "0":
+        return [LADDER[2]]
+    return list(LADDER[1:] if args.chain else LADDER)
+
+
+def _proc_start_time(pid):
+    try:
+        with open(f"/proc/{pid}/stat") as fh:
+            return fh.read().rsplit(")", 1)[1].split()[19]        # field 22: starttime in clock ticks since boot
+    except (OSError, IndexError):
+        return "0"
+
+
+def supervise_rank(args, argv):
+    """One rank's supervisor (see the comment above LADDER).  Returns the exit status of this rank."""
+    import signal
+    import socket
+    import subprocess
+    import tempfile
+
+    env0 = dict(os.environ)
+    rank, world = int(env0.get("RANK", 0)), int(env0["WORLD_SIZE"])
+    ppid = os.getppid()
+    job = env0.get("VDPP_BENCH_JOB") or f"{ppid}_{_proc_start_time(ppid)}_{env0.get('MASTER_PORT', '0')}"
+    rdv = os.path.join(tempfile.gettempdir(), f"vdpp_bench_{job}")
+    os.makedirs(rdv, exist_ok=True)
+    ladder = ladder_for(args, env0)
+    limit = max(5.0, args.watchdog)
+    proc = [None]
+
+    def on_signal(signum, _frame):          # torchrun tears a failed job down with SIGTERM: take the child along (exact PID)
+        if proc[0] is not None and proc[0].poll() is None:
+            proc[0].terminate()
+        sys.exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+
+    def put(name, text):
+        tmp = os.path.join(rdv, f".{name}.{rank}.tmp")
+        with open(tmp, "w") as fh:
+            fh.write(text)
+        os.replace(tmp, os.path.join(rdv, name))
+
+    def get(name):
+        try:
+            with open(os.path.join(rdv, name)) as fh:
+                return fh.read()
+        except OSError:
+            return None
+
+    def wait_for(name, seconds):
+        end = time.monotonic() + seconds
+        while time.monotonic() < end:
+            v = get(name)
+            if v is not None:
+                return v
+            time.sleep(0.1)
+        return None
+
+    history, rc = [], 1
+    for k, rung in enumerate(ladder):
+        env = dict(env0, VDPP_BENCH_WORKER="1", VDPP_BENCH_RUNG=rung["key"], VDPP_BENCH_ATTEMPT=str(k),
+                   VDPP_BENCH_STATUS=os.path.join(rdv, f"a{k}.r{rank}.where"), VDPP_BENCH_PREV=json.dumps(history))
+        env.update(rung["env"])
+        if k > 0:
+            # a fresh rendezvous: the agent's store still holds the failed group's keys
+            if rank == 0:
+                with socket.socket() as sock:
+                    sock.bind(("127.0.0.1", 0))
+                    put(f"a{k}.port", str(sock.getsockname()[1]))
+            port = wait_for(f"a{k}.port", 120)
+            if port is None:
+                print(f"[rank {rank}] supervisor: no port for attempt {k}; giving up", file=sys.stderr, flush=True)
+                return rc or 1
+            env["MASTER_PORT"] = port
+            env["MASTER_ADDR"] = "127.0.0.1"
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        if rank == 0 and (k > 0 or len(ladder) < len(LADDER)):
+            print(f"bench.py: attempt {k}: schedule {rung['schedule']}, transport {rung['transport']}", file=sys.stderr, flush=True)
+        cmd = [sys.executable, os.path.abspath(__file__)] + list(argv) + [f for f in rung["flags"] if f not in argv]
+        proc[0] = subprocess.Popen(cmd, env=env)
+        killed_after = None
+        while True:
+            rc = proc[0].poll()
+            if rc is not None:
+                break
+            bad = [r for r in range(world) if r != rank and (get(f"a{k}.r{r}.rc") or "0").split()[0] != "0"]
+            if bad and killed_after is None:
+                killed_after = time.monotonic() + 5.0          # a peer has failed: this attempt is lost, do not sit out the watchdog
+            if killed_after is not None and time.monotonic() > killed_after:
+                proc[0].terminate()
+                try:
+                    proc[0].wait(10)
+                except subprocess.TimeoutExpired:
+                    proc[0].kill()
+                rc = proc[0].wait()
+                if rc == 0:
+                    rc = 5
+                put(f"a{k}.r{rank}.where", f"ended by its supervisor after rank {bad[0]} failed")
+                break
+            time.sleep(0.25)
+        put(f"a{k}.r{rank}.rc", str(rc))
+        rcs = []
+        for r in range(world):
+            v = wait_for(f"a{k}.r{r}.rc", limit + 90)
+            rcs.append(int(v.split()[0]) if v is not None else -1)
+        if all(v == 0 for v in rcs):
+            return 0
+        where = {str(r): (get(f"a{k}.r{r}.where") or "").strip() for r in range(world) if rcs[r] != 0}
+        history.append({"attempt": k, "schedule": rung["schedule"], "transport": rung["transport"], "rc_per_rank": rcs,
+                        "watchdog_where": where})
+        if rank == 0:
+            print(f"bench.py: attempt {k} ({rung['key']}) FAILED: exit status per rank {rcs}, {where}", file=sys.stderr, flush=True)
+        if RC_USAGE in rcs:
+            return RC_USAGE
+        if rc == 0:
+            rc = 6                                            # this rank was fine, the job was not
+    return rc
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher around it (ref scripts/benchmark_comparison.sh:85-120 wraps
     every GPU count in torchrun; so does this): start `python -m torch.distributed.run --nproc-per-node N bench.py ...`
@@ -682,15 +903,17 @@ def launch_ranks(args, argv):
 def main():
     args = parse()
     if args.gpus < 1:
-        raise SystemExit("--gpus must be >= 1")
+        _usage("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world == args.gpus and world > 1 and os.environ.get("VDPP_BENCH_WORKER") != "1" and not args.no_fallback:
+        sys.exit(supervise_rank(args, sys.argv[1:]))        # standard library only up to here: the supervisor never touches the GPU
     if world != args.gpus:
         # never report one job size under the name of another
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} "
+        _usage(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} "
                          f"(or plain `python bench.py --gpus {args.gpus}`, which starts its own ranks)")
     rehearse = args.rehearse_cpu
     if rehearse:
@@ -700,7 +923,7 @@ def main():
     shared = os.environ.get("VDPP_SHARE_GPU") == "1"
     have = torch.cuda.device_count()
     if have < world and not shared and not rehearse:
-        raise SystemExit(f"bench.py: --gpus {world} but torch sees {have} device(s); refusing to run (rehearsal on fewer "
+        _usage(f"bench.py: --gpus {world} but torch sees {have} device(s); refusing to run (rehearsal on fewer "
                          f"cards: VDPP_SHARE_GPU=1 PIPELINE_BACKEND=gloo)")
     n = world
     # N>1: 32N videos so that filling/draining the chain (N-1 stage times inside the bracketed region: the barriers on
@@ -740,9 +963,9 @@ def main():
         ranks_seen = [None] * n
         dist.all_gather_object(ranks_seen, me)
         if dist.get_world_size() != args.gpus:
-            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+            _usage(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
         if not shared and len({(r["device"], r["uuid"]) for r in ranks_seen}) != n:
-            raise SystemExit(f"bench.py: {n} ranks but they do not sit on {n} distinct devices: {ranks_seen}")
+            _usage(f"bench.py: {n} ranks but they do not sit on {n} distinct devices: {ranks_seen}")
 
     # ---- schedule: ring by default at N > 1 (no fill / drain inside the timed region), after a self-test of its hand-off
     T = args.total_steps
@@ -750,23 +973,17 @@ def main():
     selftest = "not requested" if n > 1 else "single GPU"
     if ring:
         dog.beat("ring self-test")
-        ring = ring_selftest(rank, n, device)
+        full_limit, dog.limit = dog.limit, min(dog.limit, 30.0) if dog.limit > 0 else dog.limit
+        ring = ring_selftest(rank, n, device)      # a STALL here ends the attempt after 30 s; the supervisors then take the chain
+        dog.beat("ring self-test done")
+        dog.limit = full_limit
         selftest = "passed" if ring else "FAILED on some rank (chain schedule used)"
-    mb, conc, how_chosen, ms_table = choose_in_flight(steps, n, ring, T, args)
-    if mb < 1 or steps % mb:
-        raise SystemExit(f"bench.py: --steps {steps} videos is not a whole number of micro-batches of {mb}")
-    warmup_requested = args.warmup
-    warmup = args.warmup if args.warmup is not None else (2 * mb * conc if n == 1 else max(2 * n, 2 * mb * conc))
-    n_samples = steps // mb
-    warm_samples = -(-warmup // mb)
-    warmup = warm_samples * mb              # whole micro-batches: --warmup 5 with micro-batches of two runs 6
-
-
     from vdpp_amd.models.unet_spec import UNetConfig, forward_flops
     from vdpp_amd.hip import ops
     from vdpp_amd.models.svd_unet import StableVideoUNet
 
     lat_dtype = torch.float16
+    measured_table = None
     if rehearse:
         from vdpp_amd.models import DummyUNet
         torch.manual_seed(0)
@@ -776,6 +993,19 @@ def main():
     else:
         model = StableVideoUNet.from_random_init(StableVideoUNet._default_timestep_schedule(T), seed=0, device=device,
                                                  fp8_attention=args.fp8_attention, long_attention=False if args.no_long_attention else None)
+        if n > 1 and (args.micro_batch is None or args.concurrent is None):
+            # N > 1: how many videos a GPU keeps in flight trades a busy stage's rate against fill and drain; the four
+            # per-forward times that decide it are measured on this job's own GPUs (the static table is from a 1-GPU box)
+            measured_table = measure_in_flight_table(model, device, args, n, dog)
+    mb, conc, how_chosen, ms_table = choose_in_flight(steps, n, ring, T, args, measured_table)
+    if mb < 1 or steps % mb:
+        _usage(f"bench.py: --steps {steps} videos is not a whole number of micro-batches of {mb}")
+    warmup_requested = args.warmup
+    warmup = args.warmup if args.warmup is not None else (2 * mb * conc if n == 1 else max(2 * n, 2 * mb * conc))
+    n_samples = steps // mb
+    warm_samples = -(-warmup // mb)
+    warmup = warm_samples * mb              # whole micro-batches: --warmup 5 with micro-batches of two runs 6
+    if not rehearse:
         torch.manual_seed(args.seed)  # same dummy conditioning on every rank
         model.set_dummy_conditioning(mb, args.frames, args.height, args.width, device,
                                      guidance_scale=args.guidance_scale)
@@ -817,6 +1047,17 @@ def main():
             dist.barrier()
         sync()
 
+    # which rung of the ladder this process is (the ring may have fallen back to the chain in-process after its self-test)
+    rung_key = "ring" if ring else ("blocking" if os.environ.get("VDPP_ASYNC_COMM") == "0" else "chain")
+    # test hook (tests/test_bench_launcher_cpu.py): VDPP_BENCH_FAULT="ring:5,chain:2" parks rank 5 of the ring attempt and
+    # rank 2 of the chain attempt in front of their first hand-off, as a stalled RCCL transfer would
+    for item in filter(None, os.environ.get("VDPP_BENCH_FAULT", "").split(",")):
+        key, _, who = item.partition(":")
+        if n > 1 and key == rung_key and who.isdigit() and int(who) == rank:
+            print(f"[rank {rank}] INJECTED FAULT: parking in the {rung_key} attempt (VDPP_BENCH_FAULT)", file=sys.stderr, flush=True)
+            dog.beat(f"first hand-off of the {rung_key} schedule (injected fault: parked)")
+            while True:
+                time.sleep(1.0)
     with torch.no_grad():
         if warmup > 0:
             dog.beat("warm-up")
@@ -891,6 +1132,15 @@ def main():
             "warmup_requested": warmup_requested,     # --warmup is rounded up to whole micro-batches
             "in_flight_choice": {"micro_batch": mb, "streams": conc, "how": how_chosen, "table_ms_per_video_forward": ms_table},
             "ring_selftest": selftest,
+            # what ran before this line was produced (supervise_rank): failed attempts with their exit status per rank and
+            # where each watchdog fired, then this one
+            "attempts": json.loads(os.environ.get("VDPP_BENCH_PREV", "[]")) + [
+                {"attempt": int(os.environ.get("VDPP_BENCH_ATTEMPT", "0")),
+                 "schedule": "ring" if ring else ("chain" if n > 1 else "single GPU"),
+                 "transport": ("n/a" if n == 1 else LADDER[[r["key"] for r in LADDER].index(rung_key)]["transport"]),
+                 "rc": 0, "supervised": os.environ.get("VDPP_BENCH_WORKER") == "1"}],
+            "timestep_order": f"ascending step indices 0..{T - 1} (the reference benchmark feeds {T - 1}..0, ref "
+                              "src/modes/benchmark.py:178; the value only indexes the sigma table, every step costs the same)",
             "transport_per_rank": transports, "p2p_probe": probe,
             "world_size_seen_by_process_group": dist.get_world_size() if n > 1 else 1,
             "backend": dist.get_backend() if n > 1 else "none", "ranks": ranks_seen, "rccl_env": rccl_env,
@@ -1002,6 +1252,7 @@ def main():
                            "clock_adjusted_peak": PEAK_FP16_TFLOPS * clk_ghz / 2.4 if clk_ghz else None,
                            "frac_of_clock_adjusted_peak": (gf / gt / 1e12) / (PEAK_FP16_TFLOPS * clk_ghz / 2.4) if clk_ghz else None,
                            "traffic_source": traffic_src, "traffic_measured_at_commit": traffic_commit,
+                           "pmc_dominant_template": pmc_dominant_template(),
                            "algorithmic_bytes_per_launch": gb / gn,
                            "traffic_over_algorithmic": (traffic / (gb / gn)) if traffic else None,
                            "launches_per_forward": gn, "avg_launch_us": 1e6 * gt / gn,

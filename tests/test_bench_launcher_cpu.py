@@ -167,3 +167,53 @@ def test_eight_rank_job_through_the_launcher_on_cpu_tensors(schedule):
     assert abs(d["ms_per_step"] * d["value"] - 1e3) < 1e-6 * 1e3
     for k in range(8):
         assert f"[rank {k}/8]" in r.stderr
+
+
+def _rehearse(extra_args, env_extra, n=8, timeout=600):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VDPP_SHARE_GPU", "PIPELINE_BACKEND", "VDPP_ASYNC_COMM", "VDPP_BENCH_WORKER"):
+        e.pop(k, None)
+    e.update(env_extra)
+    return subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "16", "--warmup", "4", "--rehearse-cpu",
+                           "--frames", "4", "--height", "16", "--width", "16", "--watchdog", "6"] + extra_args,
+                          cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("fault,ends_on", [("ring:5", "chain"), ("ring:0,chain:3", "blocking")])
+def test_a_stalled_attempt_falls_back_and_the_line_records_it(fault, ends_on):
+    """The first RCCL run must not end without a number.  With N > 1 every rank is a torch-free supervisor that runs the
+    benchmark rank as a fresh child process; VDPP_BENCH_FAULT parks one rank in front of its first hand-off the way a
+    stalled RCCL transfer would (its watchdog exits it with status 3, the peers' supervisors end their ranks), and all
+    supervisors then start the next rung together on a fresh process group: ring -> chain on the side-stream link -> chain
+    on the reference's blocking send/recv (ref src/pipeline/pipeline.py:134-157).  The 8-rank job must come back with ONE
+    JSON line whose `attempts` name the failed rungs, their exit status per rank and where the watchdog fired."""
+    r = _rehearse([], {"VDPP_BENCH_FAULT": fault})
+    assert r.returncode == 0, r.stderr[-6000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    att = d["attempts"]
+    assert [a["schedule"] for a in att] == (["ring", "chain"] if ends_on == "chain" else ["ring", "chain", "chain"])
+    assert att[-1]["rc"] == 0 and att[-1]["supervised"] is True and att[-1]["attempt"] == len(att) - 1
+    parked = int(fault.split(",")[0].split(":")[1])
+    first = att[0]
+    assert first["rc_per_rank"][parked] == 3 and all(v != 0 for v in first["rc_per_rank"])
+    assert "injected fault" in first["watchdog_where"][str(parked)]
+    assert d["config"]["schedule"].startswith("chain") and d["n_gpus"] == 8 and d["value"] > 0
+    if ends_on == "blocking":
+        assert att[1]["rc_per_rank"][3] == 3 and "blocking" in att[2]["transport"]
+    assert "INJECTED FAULT" in r.stderr and "attempt 1" in r.stderr
+
+
+def test_a_job_that_cannot_succeed_on_any_rung_returns_nonzero_without_a_line():
+    r = _rehearse([], {"VDPP_BENCH_FAULT": "ring:1,chain:1,blocking:1"}, n=2)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert r.stderr.count("FAILED") >= 3
+
+
+def test_refused_arguments_are_not_retried():
+    r = _rehearse(["--micro-batch", "3"], {}, n=2)             # 16 videos are not a whole number of micro-batches of 3
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "not a whole number of micro-batches" in r.stderr
+    assert "attempt 1" not in r.stderr

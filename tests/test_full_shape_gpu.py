@@ -161,3 +161,36 @@ def test_layernorm_full_shape():
     ops.layernorm(x, gamma, beta, y, rows=rows, c=c, eps=1e-5)
     ref = F.layer_norm(x.float(), (c,), gamma, beta, eps=1e-5)
     assert rel_l2(y.float(), ref) <= 2e-3
+
+
+@pytest.mark.parametrize("inst,rows,c", [(28, 9216, 320), (28, 2304, 640)])
+def test_groupnorm_fold_linear_full_shape_two_videos(inst, rows, c):
+    """The transformer-entry GroupNorm folded into proj_in at the shapes bench.py's two-videos-per-call configuration
+    runs: 28 instances (2 videos x 14 frames) x 9,216 / 2,304 rows, one scaled weight copy per instance picked by the
+    contraction's tiles (w_group_rows).  Row sample against fp32 F.linear(F.group_norm(x)) evaluated on the GPU; every
+    instance has its own scale and offset so that a tile reading a neighbouring instance's weights fails."""
+    ops = _ops()
+    torch.manual_seed(inst + c)
+    scale = 0.5 + 1.5 * torch.rand(inst, 1, 1, device=DEV)
+    off = torch.randn(inst, 1, c, device=DEV)
+    x = (torch.randn(inst, rows, c, device=DEV) * scale + off).half()
+    gamma = 1.0 + 0.3 * torch.randn(c, device=DEV); beta = torch.randn(c, device=DEV)
+    w = (torch.randn(c, c, device=DEV) / math.sqrt(c)).half()
+    bias = torch.randn(c, device=DEV)
+    m = inst * rows
+    ws = torch.empty(ops.groupnorm_ws_bytes(inst, rows, c, 32), dtype=torch.uint8, device=DEV)
+    w_f = torch.empty(inst, c, c, dtype=torch.float16, device=DEV)
+    b_f = torch.empty(inst, c, dtype=torch.float32, device=DEV)
+    ops.groupnorm_fold_linear(x.reshape(m, c), gamma, beta, w, bias, w_f, b_f, instances=inst, rows=rows, c=c, groups=32,
+                              eps=1e-6, n=c, ws=ws, ldx=c)
+    out = torch.empty(m, c, dtype=torch.float16, device=DEV)
+    res = torch.randn(m, c, device=DEV).half()
+    ops.gemm(x.reshape(m, c), w_f, out, m=m, n=c, cin=c, bias2=b_f, bias2_rows=rows, w_group_rows=rows,
+             w_group_stride=c * c, res1=res, r1scale=1.0)
+    normed = F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, eps=1e-6).permute(0, 2, 1).reshape(m, c)
+    sel = _rows(m, 256, 7)
+    # every instance is in the sample's reach: add the first and last row of each
+    edge = torch.cat([torch.arange(inst, device=DEV) * rows, torch.arange(inst, device=DEV) * rows + rows - 1])
+    sel = torch.cat([sel, edge]).unique()
+    ref = normed[sel] @ w.float().t() + bias + res[sel].float()
+    assert rel_l2(out[sel].float(), ref) <= 3e-3

@@ -100,6 +100,105 @@ def test_step_matches_oracle_step(guidance):
         assert err <= 2e-2, f"step {step} guidance {guidance}: rel_l2={err:.3e}"
 
 
+def _per_video_oracle(ref, sample, t, ctx, ids):
+    """The fp32 oracle on every video of a batch SEPARATELY (batch-1 calls, the configuration the other oracle tests pin),
+    so that the comparison does not lean on the oracle's own batch handling; the oracle's batched call must agree."""
+    with torch.no_grad():
+        each = [ref(sample[i:i + 1].float(), t, ctx[i:i + 1].float(), ids[i:i + 1].float())[0] for i in range(sample.shape[0])]
+        both = ref(sample.float(), t, ctx.float(), ids.float())[0]
+    want = torch.cat(each, dim=0)
+    assert rel_l2(both, want) <= 1e-5, "the oracle's batched call disagrees with its per-video calls"
+    return want
+
+
+@pytest.mark.parametrize("frames,h,w,fp8", [(14, 8, 16, False), (25, 8, 8, False), (3, 16, 24, False), (14, 16, 24, True),
+                                           (25, 16, 16, True)])
+def test_unet_forward_batch2_distinct_conditioning_matches_oracle(frames, h, w, fp8):
+    """Two videos per UNet call -- what bench.py's headline configuration runs -- with DIFFERENT input latents and
+    DIFFERENT encoder_hidden_states per video, each video against its own batch-1 oracle forward.  Batch > 1 has code
+    of its own (the per-video cross-attention bias rows, the repeated frame position embedding, the time-embedding row
+    blocks, temporal attention with batch = B): a wrong row in any of them moves one video's output by O(1).
+    Tolerances as at batch 1: 2e-2 (fp16 attention), 3e-2 (fp8 attention) relative L2 PER VIDEO."""
+    from vdpp_amd.models.unet_hip import SVDUNetHIP
+    cfg, sd, ref, hip = _build(seed=41)
+    if fp8:
+        hip = SVDUNetHIP(cfg, sd, DEV, fp8_attention=True)
+        hip.FP8_MIN_SEQ = 1
+    g = torch.Generator().manual_seed(100 + frames)
+    sample = torch.randn(2, frames, 8, h, w, generator=g).half()
+    sample[1] *= 1.7                                             # the two videos differ in scale as well as in content
+    ctx = torch.randn(2, 1, cfg.cross_attention_dim, generator=g).half()
+    ids = torch.tensor([[5.0, 127.0, 0.02]]).half().repeat(2, 1)
+    t = 0.91
+    want = _per_video_oracle(ref, sample, t, ctx, ids)
+    got = hip(sample.to(DEV), t, ctx.to(DEV), ids.to(DEV))[0].float().cpu()
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    tol = 3e-2 if fp8 else 2e-2
+    for i in range(2):
+        err = rel_l2(got[i], want[i])
+        assert err <= tol, f"video {i} of the pair: rel_l2={err:.3e}"
+    # and the pair must not be two copies of one video's result (a batch index dropped somewhere)
+    assert rel_l2(got[0], want[1]) > 0.3
+    # swapping the two videos' conditioning must swap nothing but the conditioning's effect: video 0 with video 1's
+    # context differs from video 0 with its own
+    swapped = hip(sample.to(DEV), t, ctx.flip(0).to(DEV), ids.to(DEV))[0].float().cpu()
+    assert rel_l2(swapped[0], got[0]) > 1e-3, "encoder_hidden_states of video 1 never reaches video 1's rows"
+
+
+def test_unet_call_refuses_per_video_time_ids_and_timesteps():
+    """The engine evaluates the timestep / added-time embedding once per call and shares it across the batch (the
+    reference adapter feeds a scalar timestep and `added_time_ids.repeat(batch, 1)`, ref svd_unet.py:252-259,389-392):
+    rows that differ would be silently ignored, so they raise ValueError."""
+    cfg, sd, ref, hip = _build(seed=43)
+    sample = torch.zeros(2, 2, 8, 8, 8, dtype=torch.float16, device=DEV)
+    ctx = torch.zeros(2, 1, cfg.cross_attention_dim, dtype=torch.float16, device=DEV)
+    same = torch.tensor([[5.0, 127.0, 0.02]] * 2)
+    assert hip(sample, 0.5, ctx, same)[0].shape == (2, 2, 4, 8, 8)
+    assert hip(sample, torch.tensor([0.5, 0.5]), ctx, same[:1])[0].shape == (2, 2, 4, 8, 8)
+    with pytest.raises(ValueError, match="added_time_ids"):
+        hip(sample, 0.5, ctx, torch.tensor([[5.0, 127.0, 0.02], [24.0, 127.0, 0.02]]))
+    with pytest.raises(ValueError, match="added_time_ids"):
+        hip(sample, 0.5, ctx, torch.zeros(3, 3))
+    with pytest.raises(ValueError, match="timestep"):
+        hip(sample, torch.tensor([0.5, 0.7]), ctx, same)
+    with pytest.raises(ValueError, match="encoder_hidden_states"):
+        hip(sample, 0.5, ctx[:1], same)
+
+
+@pytest.mark.parametrize("guidance,batched_cfg,frames", [(None, False, 14), (3.0, False, 14), (3.0, True, 4), (None, False, 25)])
+def test_step_batch2_distinct_conditioning_matches_oracle_step(guidance, batched_cfg, frames):
+    """StableVideoUNet.forward on a micro-batch of two videos (bench.py's pipeline sample) with different CLIP
+    embeddings, image latents and input latents per video, against the oracle step of EACH video alone; guidance off,
+    3.0 sequential and 3.0 batched (UNet batch 4).  Tolerance 2e-2 relative L2 on each video's new latent."""
+    from oracle.svd_step_ref import svd_step
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+
+    cfg, sd, ref, hip = _build(seed=45)
+    steps = 25
+    model = StableVideoUNet(unet=hip, timesteps=StableVideoUNet._default_timestep_schedule(steps), batched_cfg=batched_cfg)
+    h, w = 8, 16
+    g = torch.Generator().manual_seed(77)
+    emb = torch.randn(2, 1, cfg.cross_attention_dim, generator=g).half()
+    img = torch.randn(2, 4, frames, h, w, generator=g).half()
+    img[1] *= 0.5
+    model.set_conditioning(emb.to(DEV), img.to(DEV), guidance_scale=guidance, num_frames=frames)
+    ids = torch.tensor([[5.0, 127.0, 0.02]]).half().float()
+    for step in (0, 13, 24):
+        lat = (torch.randn(2, 4, frames, h, w, generator=g) * float(model.sigmas[step] + 1)).half()
+        got = model(lat.to(DEV), step).float().cpu()
+        for i in range(2):
+            with torch.no_grad():
+                want = svd_step(ref, lat[i:i + 1].float(), step, sigmas=model.sigmas, timesteps=model.scheduler_timesteps,
+                                image_embeddings=emb[i:i + 1].float(), image_latents=img[i:i + 1].float(),
+                                added_time_ids=ids, guidance_scale=guidance, dtype=torch.float32)
+            err = rel_l2(got[i:i + 1], want)
+            assert err <= 2e-2, f"step {step} video {i} guidance {guidance}: rel_l2={err:.3e}"
+            # the UPDATE (new - old) is what a wrong conditioning row would move; the latent itself is dominated by sigma*noise
+            # (not at the last step: sigma = 0.002 there and the update is below the fp16 spacing of the latent)
+            upd_g, upd_w = got[i:i + 1] - lat[i:i + 1].float(), want - lat[i:i + 1].float()
+            assert step == 24 or rel_l2(upd_g, upd_w) <= 5e-2, f"step {step} video {i}: update off"
+
+
 def test_step_arithmetic_matches_reference_golden(golden_dir):
     """pack_input + Euler/CFG kernels vs the reference's own StableVideoUNet.forward outputs
     (tests/golden/svd_step.npz, minted with a stub UNet).  fp16 case, tolerance 2e-3 relative L2."""
@@ -523,6 +622,21 @@ def test_full_width_svd_unet_matches_oracle():
     assert torch.isfinite(got).all()
     err = rel_l2(got.float(), want)
     assert err <= 2e-2, f"full-width UNet rel_l2={err:.3e}"
+    # the same network on a PAIR of videos with different inputs and context (two videos per call is what bench.py runs):
+    # at 320 / 640 channels and 1,024 / 256 tokens per frame the transformer-entry GroupNorm is folded into per-frame
+    # weight copies (B*F = 6 instances), the per-video cross-attention bias rows and the repeated position embedding are
+    # live, and the 128x128 / split-K routes see 2x the rows
+    frames = 3
+    sample = torch.randn(2, frames, 8, h, w, generator=g).half()
+    sample[1] *= 1.5
+    ctx = torch.randn(2, 1, 1024, generator=g).half()
+    got = hip(sample.to(DEV), 0.8, ctx.to(DEV), ids.repeat(2, 1).to(DEV))[0].float().cpu()
+    want = _per_video_oracle(ref, sample, 0.8, ctx, ids.repeat(2, 1))
+    assert torch.isfinite(got).all()
+    for i in range(2):
+        err = rel_l2(got[i], want[i])
+        assert err <= 2e-2, f"full-width UNet, video {i} of a pair: rel_l2={err:.3e}"
+    assert rel_l2(got[0], want[1]) > 0.3
 
 
 @pytest.mark.parametrize("frames", [14, 25])
@@ -606,6 +720,39 @@ def test_benchmark_shape_two_kernel_routes_agree_and_are_deterministic(monkeypat
     assert torch.equal(d, e), "two launches with long_attention differ"
     err = rel_l2((d.float() - lat.float()).cpu(), upd_a)
     assert err <= 2e-3, f"long_attention changes the step at the benchmark shape: rel_l2={err:.3e}"
+
+
+@pytest.mark.parametrize("frames,steps", [(14, 25), (25, 30)])
+def test_benchmark_shape_pair_step_equals_the_two_single_video_steps(frames, steps):
+    """bench.py's headline configuration itself: ONE step on a micro-batch of two videos, latent (2,4,F,72,128), through the
+    default kernel routes, with different CLIP embeddings / image latents / input latents per video, must equal the two
+    batch-1 steps (which the fp32 oracle pins at this very size: test_benchmark_shape_unet_forward_matches_oracle) on
+    the UPDATE each applies.  Same kernels, same roundings; what differs is the tiling of 2x the rows (128x128 tiles and
+    split-K at the 4,032-row level, 28 / 50 GroupNorm-fold instances, per-video bias rows) -> tolerance 2e-3 relative L2
+    per video, and the pair must be deterministic."""
+    from vdpp_amd.models.svd_unet import StableVideoUNet
+
+    ts = StableVideoUNet._default_timestep_schedule(steps)
+    model = StableVideoUNet.from_random_init(ts, seed=0, device=DEV)
+    g = torch.Generator().manual_seed(frames)
+    emb = torch.randn(2, 1, 1024, generator=g).half().to(DEV)
+    img = torch.randn(2, 4, frames, 72, 128, generator=g).half().to(DEV)
+    step = 2
+    lat = (torch.randn(2, 4, frames, 72, 128, generator=g) * float(model.sigmas[step])).half().to(DEV)
+    model.set_conditioning(emb, img, num_frames=frames)
+    pair = model(lat, step)
+    again = model(lat, step)
+    assert torch.isfinite(pair).all() and torch.equal(pair, again)
+    upd_pair = (pair.float() - lat.float()).cpu()
+    for i in range(2):
+        model.set_conditioning(emb[i:i + 1], img[i:i + 1], num_frames=frames)
+        single = model(lat[i:i + 1].contiguous(), step)
+        upd = (single.float() - lat[i:i + 1].float()).cpu()
+        err = rel_l2(upd_pair[i:i + 1], upd)
+        print(f"{frames} frames, video {i}: pair vs single step, rel-L2 of the update {err:.3e}")
+        assert err <= 2e-3, f"video {i} of the pair differs from its batch-1 step: rel_l2={err:.3e}"
+    # the two videos' updates are different things (conditioning really is per video)
+    assert rel_l2(upd_pair[0], upd_pair[1]) > 0.3
 
 
 def test_config5_shape_fp8_attention_agrees_with_fp16():

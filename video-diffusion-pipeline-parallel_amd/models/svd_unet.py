@@ -197,7 +197,9 @@ class StableVideoUNet(nn.Module):
         dev = self.unet.device
         ids = torch.tensor([[fps - 1, motion_bucket_id, noise_aug_strength]], dtype=self.dtype, device=dev)
         self._added_time_ids = ids.repeat(batch, 1)
-        self._added_ids32 = self._added_time_ids[0].float().contiguous()
+        # every row is the same triple by construction (ref svd_unet.py:252-259 builds it the same way), so the engine
+        # evaluates the added-time embedding once per call; SVDUNetHIP.__call__ refuses rows that differ
+        self._added_ids32 = ids[0].float().contiguous()
         self._image_embeddings = image_embeddings.to(dev, self.dtype).contiguous()
         self._image_latents = image_latents.to(dev, self.dtype).contiguous()
         self._conditioning_set = True

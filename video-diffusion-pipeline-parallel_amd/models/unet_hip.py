@@ -636,9 +636,23 @@ class SVDUNetHIP:
         dev = self.device
         rows = torch.zeros((b * f * h * w, self.cin_pad), dtype=torch.float16, device=dev)
         rows[:, :c] = sample.to(dev, torch.float16).permute(0, 1, 3, 4, 2).reshape(-1, c)
-        t = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1)[:1].to(dev)
-        eps = self.forward_rows(rows, b=b, frames=f, h=h, w=w, t_value=t,
+        # ONE timestep and ONE (fps-1, motion bucket, noise aug) triple per call: the embedding MLPs run once and their
+        # result is shared by every video of the batch (what the reference adapter feeds, svd_unet.py:252-259,389-392:
+        # a scalar timestep and `added_time_ids.repeat(batch, 1)`).  Per-video values would be silently ignored -> refuse.
+        t = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1)
+        if t.numel() not in (1, b) or (t.numel() > 1 and bool((t != t[0]).any())):
+            raise ValueError("SVDUNetHIP takes one timestep per call (a scalar, or B equal values)")
+        ids = added_time_ids.to(torch.float32).reshape(-1, 3) if added_time_ids.numel() % 3 == 0 else None
+        if ids is None or ids.shape[0] not in (1, b):
+            raise ValueError(f"added_time_ids must be (B, 3) or (1, 3); got {tuple(added_time_ids.shape)}")
+        if ids.shape[0] > 1 and bool((ids != ids[0]).any()):
+            raise ValueError("SVDUNetHIP shares the added-time embedding across the batch: the rows of added_time_ids "
+                             "differ (run videos with different fps / motion bucket / noise augmentation in separate calls)")
+        if encoder_hidden_states.shape[0] != b or encoder_hidden_states[0].numel() != self.cfg.cross_attention_dim:
+            raise ValueError(f"encoder_hidden_states must be (B, 1, {self.cfg.cross_attention_dim}) with B = {b}; got "
+                             f"{tuple(encoder_hidden_states.shape)}")
+        eps = self.forward_rows(rows, b=b, frames=f, h=h, w=w, t_value=t[:1].to(dev),
                                 ctx16=encoder_hidden_states.to(dev, torch.float16).reshape(b, -1).contiguous(),
-                                added_ids32=added_time_ids.to(dev, torch.float32).reshape(-1)[:3].contiguous())
+                                added_ids32=ids[0].to(dev).contiguous())
         out = eps.reshape(b, f, h, w, -1).permute(0, 1, 4, 2, 3).contiguous()
         return (out,)
