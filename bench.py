@@ -380,7 +380,7 @@ def parse():
     ap.add_argument("--emit-frames", action="store_true",
                     help="also time the pipeline WITH its last edge stage (secondary figure `frames_out`, never `value`): every "
                          "finished latent is decoded to frames by the temporal VAE on a stream of its own beside the UNet "
-                         "steps, pipeline sample i on rank i mod N (models/edge_stages.py::FrameEmitter; ref "
+                         "steps, on the rank where it finishes (models/edge_stages.py::FrameEmitter; ref "
                          "scripts/generate_video_demo.py:418).  Default at N = 1 unless --no-decode; opt-in at N > 1")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="NOT a measurement: run this script's whole multi-rank path (launcher, process group, rotating "
@@ -543,9 +543,10 @@ def vae_decode_leg(device, frames, h, w):
 def frames_out_leg(args, stage, supplier, device, n, rank, ring, mb, conc, fence, dog):
     """The same pipeline with its last edge stage attached (secondary figure, never `value`): every finished pipeline
     sample is decoded to frames (B,3,F,8H,8W) fp32 by the temporal VAE (random weights of the SVD architecture) on a HIP
-    stream of its own beside the UNet steps, sample i on rank i mod N -- the last rank forwards the 1-2 MB latent -- so that
-    no stage carries a whole decode per video (ref scripts/generate_video_demo.py:418 decodes on the last rank, after the
-    loop).  Barrier-bracketed like the headline figure; the last decode's completion is inside the timed region."""
+    stream of its own beside the UNet steps, on the rank where it finishes: with the ring schedule that is rank (i mod N) - 1,
+    so no stage carries a whole decode per video; with the chain it is the last rank (ref scripts/generate_video_demo.py:418
+    decodes there too, after the loop).  No finished latent is forwarded (models/edge_stages.py says why).  Barrier-bracketed
+    like the headline figure; the last decode's completion is inside the timed region."""
     from vdpp_amd.models.edge_stages import FrameEmitter
     from vdpp_amd.models.vae_hip import TemporalDecoderHIP, VAEDecoderConfig, random_state_dict
 
@@ -586,7 +587,8 @@ def frames_out_leg(args, stage, supplier, device, n, rank, ring, mb, conc, fence
     torch.cuda.empty_cache()
     return {"videos_per_s": videos / dt, "ms_per_video": 1e3 * dt / videos, "videos": videos,
             "decodes_per_rank_incl_warmup": decoded, "frames_per_sample": shape, "output_dtype": "fp32",
-            "where": "pipeline sample i is decoded on rank i mod N, on a HIP stream of its own beside the UNet steps"
+            "where": ("every sample is decoded on the rank where it finishes (" + ("ring: rank (i mod N) - 1" if ring else
+                      "chain: the last rank") + "), on a HIP stream of its own beside the UNet steps")
                      if n > 1 else "on a HIP stream of its own beside the UNet steps of the following videos",
             "note": "temporal VAE decoder with random weights of the SVD architecture; NOT `value`: the reference benchmark's "
                     "videos end as latents (ref src/modes/benchmark.py), its demo decodes them on the last rank "

@@ -326,3 +326,86 @@ def test_simulator_cli_is_reproducible_across_world_sizes(tmp_path):
         assert m, r.stderr[-2000:]
         norms.append(float(m.group(1)))
     assert norms[0] == norms[1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Hand-off ORDER under RCCL's rules (tests/p2p_emulation.py): one FIFO per rank pair and side, both directions in it, tags
+# ignored, a transfer only when a send at one head meets a receive at the other.  Gloo cannot fail these; RCCL hangs.
+# ---------------------------------------------------------------------------------------------------------------------
+def _threads_as_ranks(world, fn, timeout=180):
+    import threading
+    results, errors = {}, []
+
+    def main(rank):
+        try:
+            results[rank] = fn(rank)
+        except Exception as exc:       # noqa: BLE001  (reported in the main thread)
+            errors.append((rank, repr(exc)))
+
+    ts = [threading.Thread(target=main, args=(r,)) for r in range(world)]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=timeout)
+    assert all(not t.is_alive() for t in ts), f"a rank is stuck; errors so far: {errors}"
+    return results, errors
+
+
+@pytest.mark.parametrize("world,num_samples,conc,ring", [(2, 5, 1, True), (2, 6, 2, True), (3, 7, 2, True), (4, 9, 1, True),
+                                                        (8, 20, 2, True), (2, 4, 1, False), (3, 5, 1, False), (4, 6, 1, False)])
+def test_handoff_order_is_safe_under_rccl_pair_fifo_rules(monkeypatch, golden_dir, world, num_samples, conc, ring):
+    """Ring and chain schedules with ranks as threads over the pair-FIFO transport: no pair may ever have two sends or two
+    receives facing each other, every operation must be met, results == the plain loop bit for bit, and (N > 2) no rank
+    pair may carry traffic in both directions at all -- the property that makes an order crossing impossible."""
+    import vdpp_amd.pipeline.pipeline as pl
+    from tests.p2p_emulation import PairFifoTransport
+
+    net = PairFifoTransport(timeout=60)
+    net.install(monkeypatch, pl.dist)
+    z, model = _load(golden_dir, "dummy_c4h64.npz", 4, 64)
+    x = torch.from_numpy(z["input"])[:, :, :2, :8, :8].contiguous()
+    ts = [6, 5, 4, 3, 2, 1, 0, 7, 9]                             # 9 steps: uneven over every world size tried
+    spec = LatentSpec(shape=x.shape, dtype=torch.float32, device=torch.device("cpu"))
+    quiet = logging.getLogger("quiet"); quiet.setLevel(logging.ERROR)
+
+    def rank_main(rank):
+        net.bind(rank)
+        stage = PipelineStage(model, PipelineConfig(total_steps=len(ts), world_size=world, rank=rank, timesteps=ts,
+                                                    latent_spec=spec, balanced=True, ring=ring, rotate=not ring,
+                                                    concurrent_samples=conc), logger=quiet)
+        with torch.no_grad():
+            return stage.run_many(num_samples, input_supplier=(lambda i: x * (i + 1)) if (ring or rank == 0) else None)
+
+    results, errors = _threads_as_ranks(world, rank_main)
+    assert not errors, errors
+    assert net.crossed is None and net.idle()
+    outs = results[world - 1]
+    assert len(outs) == num_samples and all(results[r] is None for r in range(world - 1))
+    for i, got in enumerate(outs):
+        lat = x * (i + 1)
+        with torch.no_grad():
+            for s in ts:
+                lat = model(lat, s)
+        assert torch.equal(got, lat), f"sample {i}"
+    both_ways = {p: d for p, d in net.directions_per_pair().items() if len(d) > 1}
+    if world > 2:
+        assert not both_ways, f"pairs with traffic in both directions: {both_ways}"
+    elif ring:
+        assert set(both_ways) == {(0, 1)}                       # N = 2: one peer, one communicator -- ordered by the even/odd rule
+
+
+def test_pair_fifo_rules_catch_the_round_4_frame_forwarding_order():
+    """The detector detects: the order ADVICE r04 found in FrameEmitter's removed forwarding -- on the pair (N-2, N-1) the last
+    rank issues recv, recv, send(finished) while rank N-2 issues recv(finished), send, send -- is a crossing."""
+    from tests.p2p_emulation import P2POrderError, PairFifoTransport
+
+    net = PairFifoTransport(timeout=5)
+    t = torch.zeros(4)
+    net.bind(1)                       # "last rank": two pre-posted stage receives, then the forward of a finished latent
+    net.irecv(t.clone(), 0); net.irecv(t.clone(), 0); net.isend(t, 0)
+    net.bind(0)                       # "rank N-2": the receive of that forward first, then its two stage sends
+    with pytest.raises(P2POrderError, match="both sides have receives"):
+        net.irecv(t.clone(), 1)
+    assert net.crossed
+    ok = PairFifoTransport(timeout=5)
+    ok.bind(1); ok.irecv(t.clone(), 0); w = ok.isend(t + 1, 0)
+    ok.bind(0); ok.isend(t + 2, 1); buf = t.clone(); ok.irecv(buf, 1).wait()
+    assert w.is_completed() and ok.idle() and float(buf[0]) == 1.0

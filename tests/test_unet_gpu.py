@@ -448,20 +448,6 @@ def test_interleaved_run_many_equals_sequential():
             assert torch.equal(a, b)
 
 
-class _FakeWork:
-    def __init__(self, fn=None):
-        self._fn = fn
-
-    def wait(self):
-        if self._fn is not None:
-            self._fn()
-            self._fn = None
-        return True
-
-    def is_completed(self):
-        return True
-
-
 @pytest.mark.parametrize("conc,rotate,mb", [(1, False, 1), (2, False, 1), (3, False, 1), (2, True, 1), (2, True, 2), (1, False, 2)])
 def test_side_stream_link_with_emulated_stream_ordered_p2p(monkeypatch, conc, rotate, mb):
     """Two pipeline ranks emulated in ONE process on one GPU: torch.distributed isend/irecv are replaced by
@@ -473,24 +459,11 @@ def test_side_stream_link_with_emulated_stream_ordered_p2p(monkeypatch, conc, ro
     from vdpp_amd.models.svd_unet import StableVideoUNet
     from vdpp_amd.pipeline import LatentSpec, PipelineConfig, PipelineStage
 
-    mailbox = []          # FIFO of (tensor, ready_event) from rank 0 to rank 1
-
-    def fake_isend(tensor, dst, tag=0):
-        ev = torch.cuda.Event()
-        staged = tensor.clone()                 # on the issuing (side) stream, ordered behind its wait_event
-        ev.record(torch.cuda.current_stream())
-        mailbox.append((staged, ev))
-        return _FakeWork()
-
-    def fake_irecv(buf, src, tag=0):
-        def complete():                          # runs inside work.wait() on the link's side stream
-            staged, ev = mailbox.pop(0)
-            torch.cuda.current_stream().wait_event(ev)
-            buf.copy_(staged)
-        return _FakeWork(complete)
-
-    monkeypatch.setattr(pl.dist, "isend", fake_isend)
-    monkeypatch.setattr(pl.dist, "irecv", fake_irecv)
+    # RCCL's rules for un-batched P2P (tests/p2p_emulation.py): per rank pair ONE queue per side holding both directions,
+    # tags ignored, a transfer when a send at one head meets a receive at the other; copies are stream-ordered
+    from tests.p2p_emulation import PairFifoTransport
+    net = PairFifoTransport(timeout=60)
+    net.install(monkeypatch, pl.dist)
 
     cfg, sd, ref, hip = _build(seed=29)
     steps = 5
@@ -507,14 +480,16 @@ def test_side_stream_link_with_emulated_stream_ordered_p2p(monkeypatch, conc, ro
                                                    async_comm=world > 1, concurrent_samples=conc,
                                                    rotate=rotate and world > 1))
 
+    net.bind(0)
     want = stage(0, 1).run_many(5, input_supplier=lambda i: xs[i])
     r0, r1 = stage(0, 2), stage(1, 2)
     assert (r0.step_range.count, r1.step_range.count) == (3, 2)
-    assert r0.run_many(5, input_supplier=lambda i: xs[i]) is None     # rank 0: everything goes to the mailbox
+    assert r0.run_many(5, input_supplier=lambda i: xs[i]) is None     # rank 0: five sends queued towards rank 1
+    net.bind(1)
     got = r1.run_many(5)
     r0.drain(); r1.drain()
     torch.cuda.synchronize()
-    assert not mailbox and len(got) == 5
+    assert net.crossed is None and net.idle() and len(got) == 5
     for a, b in zip(want, got):
         assert torch.equal(a, b)
 
@@ -525,34 +500,15 @@ def test_ring_schedule_with_emulated_stream_ordered_p2p(monkeypatch, world, num_
     on one GPU; `isend` / `irecv` are replaced by stream-ordered mailbox copies per directed link (what an RCCL
     send/recv provides).  Exercises the event choreography of `_run_many_ring` (compute lanes -> side stream ->
     compute lanes), the interleaved lanes and the final collection, and checks every sample == the 1-rank result."""
-    import collections
-    import queue
     import threading
 
     import vdpp_amd.pipeline.pipeline as pl
     from vdpp_amd.models.svd_unet import StableVideoUNet
     from vdpp_amd.pipeline import LatentSpec, PipelineConfig, PipelineStage
 
-    links = collections.defaultdict(queue.Queue)          # (src, dst) -> FIFO of (tensor, ready_event)
-    me = threading.local()
-
-    def fake_isend(tensor, dst, tag=0):
-        ev = torch.cuda.Event()
-        staged = tensor.clone()                            # on the issuing stream, ordered behind its wait_event
-        ev.record(torch.cuda.current_stream())
-        links[(me.rank, dst)].put((staged, ev))
-        return _FakeWork()
-
-    def fake_irecv(buf, src, tag=0):
-        def complete():                                    # runs inside work.wait() on the issuing (side) stream
-            staged, ev = links[(src, me.rank)].get(timeout=120)
-            torch.cuda.current_stream().wait_event(ev)
-            buf.copy_(staged)
-        return _FakeWork(complete)
-
-    monkeypatch.setattr(pl.dist, "isend", fake_isend)
-    monkeypatch.setattr(pl.dist, "irecv", fake_irecv)
-    monkeypatch.setattr(pl.dist, "is_initialized", lambda: False)     # (no process group: plain stream-ordered mailboxes)
+    from tests.p2p_emulation import PairFifoTransport
+    net = PairFifoTransport(timeout=120)                  # RCCL's pair-FIFO rules; world 2: both directions on ONE queue pair
+    net.install(monkeypatch, pl.dist)
 
     cfg, sd, ref, hip = _build(seed=31)
     steps = 7
@@ -573,7 +529,7 @@ def test_ring_schedule_with_emulated_stream_ordered_p2p(monkeypatch, world, num_
 
     def rank_main(rank):
         try:
-            me.rank = rank
+            net.bind(rank)
             torch.cuda.set_device(0)
             with torch.no_grad():
                 results[rank] = stage(rank, world, True).run_many(num_samples, input_supplier=lambda i: xs[i])
@@ -586,7 +542,9 @@ def test_ring_schedule_with_emulated_stream_ordered_p2p(monkeypatch, world, num_
     for t in threads: t.join(timeout=300)
     assert not errors, errors
     assert all(not t.is_alive() for t in threads), "a rank is stuck"
-    assert all(q.empty() for q in links.values())
+    assert net.crossed is None and net.idle()
+    if world > 2:
+        assert all(len(d) == 1 for d in net.directions_per_pair().values()), "a rank pair carried traffic in both directions"
     assert all(results[r] is None for r in range(world - 1))
     got = results[world - 1]
     assert len(got) == num_samples

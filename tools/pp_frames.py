@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The step pipeline WITH its last edge stage: WORLD_SIZE ranks (sharing the cards that exist, Gloo hand-off) push K toy
-videos through a small SVD UNet and a small temporal VAE decoder; models/edge_stages.py::FrameEmitter decodes the finished
-latent of sample i on rank i mod N (the last rank forwards it), beside the UNet steps, on a stream of its own.  Every rank
+videos through a small SVD UNet and a small temporal VAE decoder; models/edge_stages.py::FrameEmitter decodes every finished
+latent on the rank where it finished (ring: rank (i mod N) - 1; chain: the last rank), beside the UNet steps, on a stream of
+its own -- no finished latent is ever forwarded.  Every rank
 writes {sample index: frames} of what IT decoded to --out-dir/rank<r>.pt.  Run at world sizes 1, 2, 3 the union of the
 files must be bit-identical, and equal to decode_latents of the plain loop's latents (tests/test_modes_gpu.py).
 usage: pp_frames.py --out-dir DIR [--samples 5] [--schedule rotate|chain|ring] [--concurrent 2] [--no-spread]"""

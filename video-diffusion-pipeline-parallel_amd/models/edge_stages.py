@@ -97,30 +97,31 @@ class FrameEmitter:
     """``decode_latents`` wired into the step pipeline, so that the node emits frames (ref
     ``scripts/generate_video_demo.py:418`` decodes every finished latent on the LAST rank, after the step loop).
 
-    The temporal-VAE decode of one video costs about as much as a whole stage of an 8-GPU pipeline (three UNet steps), so
-    run where the reference runs it -- on the last rank -- it would halve the node's rate.  Here (``spread=True``) the
-    finished latent of pipeline sample ``i`` is decoded by rank ``i mod N``: the last rank forwards it with the same
-    point-to-point transport the stages use (one more 1-2 MB message per video), every rank decodes on a HIP stream of
-    its own BESIDE its UNet steps, and per video each GPU carries 1/N of a decode instead of one GPU carrying all of it.
-    With the ring schedule a video finishes on rank ``(i mod N) - 1`` and is decoded right there.  ``spread=False`` is
-    the reference's arrangement (everything on the last rank).
+    The temporal-VAE decode of one video costs about as much as a whole stage of an 8-GPU pipeline (three UNet steps).
+    Every rank decodes what FINISHES on it, on a HIP stream of its own BESIDE its UNet steps, and never moves a finished
+    latent:
+
+      * ring schedule (``bench.py``'s default at N > 1): sample ``i`` finishes on rank ``(i mod N) - 1`` and is decoded
+        right there, so per video each GPU carries 1/N of a decode;
+      * chain of stages: everything finishes, and is decoded, on the last rank -- the reference's arrangement.
+
+    Until round 4 the chain could also spread its decodes (sample ``i`` on rank ``i mod N``, the last rank forwarding the
+    latent with ``isend(tag=7001)``).  That was removed: RCCL ignores tags and orders the un-batched P2P of a rank PAIR on
+    one internal stream, so on the pair (N-2, N-1) the forwards shared a communicator with the stage hand-offs and, with
+    two samples interleaved per rank, the two sides could issue the two directions in different orders (last rank:
+    recv, recv, send -- rank N-2: recv, send, send) and wait for each other for ever.  Over Gloo (tags honoured, host
+    threads) this cannot show.  Now no message exists whose order could cross: ``spread`` is accepted for older call
+    sites and means "decode where the sample finishes", which balances the ring and leaves the chain on its last rank.
 
     Attach to a stage on EVERY rank (same arguments), run the pipeline, then ``finish(num_samples)``:
 
         emitter = FrameEmitter(decoder, stage, num_frames)            # every rank
         stage.run_many(K, input_supplier=...); stage.drain()
         frames = emitter.finish(K)                                    # {sample index: (B,3,F,8H,8W) fp32} decoded HERE
-
-    A receive for a forwarded latent is posted when this rank has issued the sample that the last rank is finishing at
-    about that moment (``i + N-1-rank``), not earlier: a parked RCCL receive is a resident kernel.  Over Gloo with GPU
-    latents (rehearsal on a shared card) the events are waited for on the host, as in ``pipeline._SideStreamLink``.
     """
-
-    TAG = 7001
 
     def __init__(self, decoder: TemporalDecoderHIP, stage, num_frames: int, *, decode_chunk_size: int = 14,
                  spread: bool = True, keep: str = "all", check_finite: bool = False) -> None:
-        import torch.distributed as dist
         from ..pipeline.step_assignment import ring_finish_rank
 
         if keep not in ("all", "last", "none"):
@@ -130,70 +131,28 @@ class FrameEmitter:
         cfg = stage.config
         self.rank, self.world = cfg.rank, cfg.world_size
         self.ring = bool(cfg.ring and cfg.world_size > 1)
-        self.spread = bool(spread and self.world > 1 and not self.ring)
-        self.spec = cfg.latent_spec
+        self.spread = bool(spread and self.ring)         # decodes are spread exactly when the schedule spreads the finishes
         self.device = decoder.device
         self.stream = torch.cuda.Stream(device=self.device)          # decodes
-        self.side = torch.cuda.Stream(device=self.device) if self.world > 1 else None      # forwards
-        self.host_ordered = self.world > 1 and dist.is_initialized() and dist.get_backend() == "gloo"
-        self._dist, self._ring_finish_rank = dist, ring_finish_rank
+        self._ring_finish_rank = ring_finish_rank
         self.frames: dict[int, torch.Tensor] = {}
-        self._next_recv = self.rank              # next sample this rank is to receive (spread mode, not the last rank)
-        self._issued = -1                        # highest sample index this rank has issued
-        self._in_flight: list = []
-        self.stats = {"decoded": 0, "forwarded": 0, "received": 0}
+        self.stats = {"decoded": 0, "forwarded": 0, "received": 0}   # (forwarded / received stay 0: kept for older readers)
         stage.finished_latent_hook = self._finished
-        stage.after_sample_hook = self._after_sample
+        stage.after_sample_hook = None
 
     # ---------------------------------------------------------------- who decodes sample i
     def decoder_rank(self, idx: int) -> int:
-        if self.ring:
-            return self._ring_finish_rank(idx, self.world)
-        return idx % self.world if self.spread else self.world - 1
+        """The rank on which sample idx's last step runs."""
+        return self._ring_finish_rank(idx, self.world) if self.ring else self.world - 1
 
-    # ---------------------------------------------------------------- hooks
+    # ---------------------------------------------------------------- hook
     def _finished(self, idx: int, latent: torch.Tensor) -> None:
         """On the rank (and stream) where sample idx's last step was just enqueued."""
-        target = self.decoder_rank(idx)
-        if target == self.rank:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(self.device))
-            self._decode(idx, latent, ready)
-            return
+        if self.decoder_rank(idx) != self.rank:
+            raise RuntimeError(f"sample {idx} finished on rank {self.rank}, the schedule names rank {self.decoder_rank(idx)}")
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))
-        latent.record_stream(self.side)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ready)
-            if self.host_ordered:
-                ready.synchronize()
-            work = self._dist.isend(latent, dst=target, tag=self.TAG)
-        self._in_flight.append((work, latent))
-        self.stats["forwarded"] += 1
-
-    def _after_sample(self, idx: int) -> None:
-        self._issued = max(self._issued, idx)
-        if self.spread and self.rank != self.world - 1:
-            # the last rank is finishing sample j about when this rank issues sample j + (N-1-rank)
-            while self._next_recv + (self.world - 1 - self.rank) <= self._issued:
-                self._receive(self._next_recv)
-                self._next_recv += self.world
-
-    def _receive(self, idx: int) -> None:
-        buf = self.spec.empty()
-        buf.record_stream(self.side)
-        allocated = torch.cuda.Event()
-        allocated.record(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(allocated)
-            if self.host_ordered:
-                allocated.synchronize()
-            work = self._dist.irecv(buf, src=self.world - 1, tag=self.TAG)
-            work.wait()                          # RCCL: orders the side stream; Gloo: blocks the host until it has landed
-            landed = torch.cuda.Event()
-            landed.record(self.side)
-        self.stats["received"] += 1
-        self._decode(idx, buf, landed)
+        self._decode(idx, latent, ready)
 
     def _decode(self, idx: int, latent: torch.Tensor, ready) -> None:
         latent.record_stream(self.stream)
@@ -208,17 +167,8 @@ class FrameEmitter:
 
     # ---------------------------------------------------------------- end of a run
     def finish(self, num_samples: int) -> dict:
-        """Post what is still to be received (the pipeline's tail), wait for this rank's decodes and forwards, and return
-        ``{sample index: frames}`` for the samples decoded on THIS rank (``keep``: all of them, the last one, or none)."""
-        if self.spread and self.rank != self.world - 1:
-            while self._next_recv < num_samples:
-                self._receive(self._next_recv)
-                self._next_recv += self.world
-        for work, _ in self._in_flight:
-            work.wait()
-        self._in_flight.clear()
-        if self.side is not None:
-            self.side.synchronize()
+        """Wait for this rank's decodes and return ``{sample index: frames}`` for the samples decoded on THIS rank
+        (``keep``: all of them, the last one, or none)."""
         self.stream.synchronize()
         if self.check_finite:
             for idx, out in self.frames.items():
@@ -229,4 +179,3 @@ class FrameEmitter:
     def reset(self) -> None:
         """Forget the previous run's bookkeeping (bench.py: warm-up, then the timed region)."""
         self.frames = {}
-        self._next_recv, self._issued = self.rank, -1
