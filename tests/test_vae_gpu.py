@@ -65,6 +65,105 @@ def test_softmax_rows_survives_scores_that_overflowed_fp16():
     assert rel_l2(got[0], torch.softmax(x[0].float(), -1)) <= 2e-3 and rel_l2(got[5], torch.softmax(x[5].float(), -1)) <= 2e-3
 
 
+def test_softmax_rows_keeps_a_nan_a_nan():
+    """The saturation above clamps infinities only: a NaN score (an upstream inf - inf) must still poison its row, so that
+    decode_latents(check_finite=True) can see the fault."""
+    ops = _ops()
+    x = torch.randn(3, 256).half()
+    x[1, 17] = float("nan")
+    xd = x.to(DEV)
+    ops.softmax_rows(xd, rows=3, cols=256)
+    got = xd.float().cpu()
+    assert torch.isfinite(got[0]).all() and torch.isfinite(got[2]).all()
+    assert torch.isnan(got[1]).any()
+
+
+@pytest.mark.parametrize("m,n,k,lda", [(512, 256, 64, None), (300, 512, 512, None), (1000, 768, 128, 192)])
+def test_gemm_f32out_is_the_raw_fp32_product(m, n, k, lda):
+    """sp_gemm_f32out_f16: D = A W^T as raw fp32 sums (no rounding to fp16 anywhere), ragged m, A with a row pitch."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(m + n)
+    a = torch.randn(m, lda or k, generator=g).half()
+    w = torch.randn(n, k, generator=g).half()
+    out = torch.full((m, n), -7.0, dtype=torch.float32, device=DEV)
+    ops.gemm_f32out(a.to(DEV)[:, :k], w.to(DEV), out, m=m, n=n, k=k, lda=lda or k)
+    want = a[:, :k].double() @ w.double().t()
+    err = (out.double().cpu() - want).abs().max() / want.abs().max()
+    assert float(err) <= 1e-5, f"fp32 product off: {float(err):.2e}"            # fp32 accumulation of exact fp16 products
+    with pytest.raises(ops.HipKernelError, match="multiple of 256"):
+        ops.gemm_f32out(a.to(DEV)[:, :k], w.to(DEV)[:100], out, m=m, n=100, k=k, lda=lda or k)
+
+
+@pytest.mark.parametrize("rows,cols,inplace", [(5, 256, True), (9, 2304, True), (4, 9216, True), (6, 1024, False)])
+def test_softmax_rows_f32(rows, cols, inplace):
+    """fp32 logits -> fp16 probabilities, also IN PLACE over the front of each row's logits (ldo = 2 * ld); logits far
+    outside fp16's range (+-3e5) and logits whose differences fp16 could not hold near 60,000 are handled exactly."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows * cols)
+    x = torch.randn(rows, cols, generator=g) * 50.0
+    x[0] = x[0] * 6000.0                                     # |logit| up to ~1e6
+    x[1] = 60000.0 + torch.randn(cols, generator=g) * 3.0    # fp16 spacing at 60,000 is 32: the differences would vanish
+    x[2, 5] = 2.0e5                                          # one dominant logit beyond fp16's largest number
+    scale = 0.37
+    xd = x.to(DEV)
+    if inplace:
+        out = xd.view(torch.float16)
+        ops.softmax_rows_f32(xd, out, rows=rows, cols=cols, scale=scale, ld=cols, ldo=2 * cols)
+        got = out[:, :cols].float().cpu()
+    else:
+        out = torch.full((rows, cols + 8), 3.0, dtype=torch.float16, device=DEV)
+        ops.softmax_rows_f32(xd, out, rows=rows, cols=cols, scale=scale)
+        got = out[:, :cols].float().cpu()
+        assert float((out[:, cols:].float() - 3.0).abs().max()) == 0.0 and torch.equal(xd.cpu(), x)
+    want = torch.softmax(x.double() * scale, dim=-1).float()
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) <= 1e-3 and rel_l2(got, want) <= 2e-3
+    assert float(got[2, 5]) == 1.0
+    with pytest.raises(ops.HipKernelError, match="in place"):
+        ops.softmax_rows_f32(xd, xd.view(torch.float16), rows=rows, cols=cols, ld=cols, ldo=cols)
+
+
+def test_mid_block_attention_with_logits_beyond_fp16():
+    """The decoder's single-head attention on inputs whose logits reach ~+-1.4e5 -- past fp16's 65,504, with rival keys
+    only a few units apart: what trained weights can produce and why the reference upcasts this VAE to fp32
+    (scripts/generate_video_demo.py:171-175).  With fp32 logits (round 5) the block matches an fp64 evaluation to 2e-2;
+    the fp16-score composition (VDPP_VAE_FP16_SCORES=1 / fp32_scores=False) can only saturate and must be visibly wrong
+    on the same input, which is what makes this a test of the new path."""
+    from vdpp_amd.models.vae_hip import TemporalDecoderHIP, VAEDecoderConfig, random_state_dict
+    cfg = VAEDecoderConfig.tiny(64)
+    sd = random_state_dict(cfg, seed=5)
+    dec = TemporalDecoderHIP(cfg, sd, DEV)
+    p = dec.mid[1]
+    c, n_img, hw = p["c"], 2, 256
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n_img * hw, c, generator=g).half()
+    # blow the q / k projections up so that q.k / sqrt(c) spans +-4e5 while q, k themselves stay inside fp16
+    for name, f in (("q", 300.0), ("k", 300.0)):
+        p[name].w = (p[name].w.float() * f).half()
+        p[name].bias = p[name].bias * f
+    assert dec.fp32_scores
+    got32 = dec._run_attn(p, x.to(DEV), n_img, hw).float().cpu()
+    dec.fp32_scores = False
+    got16 = dec._run_attn(p, x.to(DEV), n_img, hw).float().cpu()
+    dec.fp32_scores = True
+    # fp64 reference of the same block on the same fp16-rounded weights
+    xn = F.group_norm(x.double().reshape(n_img, hw, c).permute(0, 2, 1), cfg.norm_groups,
+                      p["norm"].g.double().cpu(), p["norm"].b.double().cpu(), eps=p["norm"].eps).permute(0, 2, 1)
+    xn = xn.half().double()                                                   # the engine stores the normalised rows in fp16
+    q = (xn @ p["q"].w.double().cpu().t() + p["q"].bias.double().cpu()).half().double()
+    k = (xn @ p["k"].w.double().cpu().t() + p["k"].bias.double().cpu()).half().double()
+    v = xn @ p["wv"].double().cpu().t() + p["bv"].double().cpu()
+    logits = q @ k.transpose(1, 2) / (c ** 0.5)
+    assert float(logits.abs().max()) > 1e5, "the test input no longer leaves fp16's range (65,504)"
+    o = torch.softmax(logits, dim=-1) @ v
+    want = (o.reshape(n_img * hw, c).half().double() @ p["out"].w.double().cpu().t() + p["out"].bias.double().cpu()
+            + x.double()).float()
+    e32, e16 = rel_l2(got32, want), rel_l2(got16, want)
+    print(f"mid-block attention, logits up to {float(logits.abs().max()):.3g}: fp32 logits rel-L2 {e32:.2e}, fp16 scores {e16:.2e}")
+    assert torch.isfinite(got32).all() and e32 <= 2e-2
+    assert e16 > 5 * e32, "the fp16-score path should not be able to follow these logits"
+
+
 def test_softmax_rows_rejects_bad_shapes():
     ops = _ops()
     x = torch.zeros(4, 24, dtype=torch.float16, device=DEV)

@@ -19,7 +19,7 @@
 // blocks only (a workgroup whose word is zero exits at once), which overwrites their rows.  So results never depend on
 // the speculation, only the time does: nothing flagged costs one near-empty launch.  The cost of a wrong guess is
 // BOUNDED (round 4): flagging waves also count themselves in one more word behind the flag words, every workgroup reads
-// that word when it starts, and once LONG_BAIL waves have flagged, a starting workgroup only raises its own flag word
+// that word when it starts, and once 1/16 of the call's waves (at least 64) have flagged, a starting workgroup only raises its own flag word
 // and exits -- data on which the frozen reference keeps failing is handed to the ordinary kernel after the first round
 // of workgroups (256 of the 2,520 of a level-0 call) instead of being computed twice: everything flagged costs ~1.1x
 // the ordinary kernel (it was 2.1x), measured by tests/test_kernels_gpu.py::test_attention_spatial_long_second_pass
@@ -54,8 +54,12 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// waves that may flag before starting workgroups stop trying (a level-0 call of the UNet has 10,080 - 20,160 waves)
-constexpr unsigned LONG_BAIL = 64;
+// Waves that may flag before starting workgroups stop trying: 1/16 of the call's waves, between 64 and 512 (a level-0 call
+// of the UNet has 10,080 - 20,160 waves -> 512, reached inside the first round of 256 workgroups = 1,024 waves when the
+// frozen reference fails everywhere, so the worst case stays one round + the ordinary kernel).  A fixed 64 (round 4) also
+// gave up on data where under 1 % of the rows flag, which then cost ~1.1x instead of ~1.0x; with a fraction, scattered
+// failures below 6 % are recomputed block by block and everything else keeps the fast path.
+constexpr unsigned LONG_BAIL_MIN = 64, LONG_BAIL_MAX = 512;   // (512: half of the first round's 1,024 waves on 256 CUs)
 
 template <int QB>
 __global__ __launch_bounds__(256, 1) void attn_long_kernel(
@@ -80,7 +84,10 @@ __global__ __launch_bounds__(256, 1) void attn_long_kernel(
     __syncthreads();
     const unsigned seen = *(volatile unsigned *)smem;
     __syncthreads();                         // (the ring's first LDS-DMA piece lands on this word)
-    if (seen >= LONG_BAIL) {
+    const unsigned total_waves = gridDim.x * gridDim.y * 4u;
+    const unsigned frac = total_waves / 16u;
+    const unsigned bail = frac < LONG_BAIL_MIN ? LONG_BAIL_MIN : (frac > LONG_BAIL_MAX ? LONG_BAIL_MAX : frac);
+    if (seen >= bail) {
       if (tid == 0) flags[(int64_t)bh * gridDim.x + blockIdx.x] = 1u;   // the second pass computes this block
       return;
     }
@@ -488,7 +495,7 @@ int sp_attn_spatial_launch(const void *q, const void *k, const void *v, void *o,
                            const unsigned *only_flagged, void *stream, const char *who);
 
 // bytes of workspace sp_attn_spatial_long_f16 needs: one word per 256 query rows of every (batch item, head), and one
-// more behind them that counts the waves that flagged (LONG_BAIL)
+// more behind them that counts the waves that flagged (the bail-out threshold reads it)
 extern "C" int64_t sp_attn_long_ws_bytes(int batch, int seq, int heads) {
   if (batch <= 0 || seq <= 0 || heads <= 0) return 0;
   return ((int64_t)batch * heads * ((seq + LONG_ROWS - 1) / LONG_ROWS) + 1) * (int64_t)sizeof(unsigned);

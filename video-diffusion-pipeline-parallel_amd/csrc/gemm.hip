@@ -667,6 +667,25 @@ extern "C" int sp_gemm_set_route(int route, int bm, int bn) {
   return SP_OK;
 }
 
+// D[m][n] (fp32, row pitch n) = A[m][k] . W[n][k]^T: the raw fp32 sums, never rounded to fp16.  The 256 x 256 ping-pong
+// kernel in its K-slice form with ONE slice (the accumulators leave as 16-byte fp32 stores; no bias, no epilogue).
+// Used where the product feeds a softmax whose logits must not pass through fp16: the temporal VAE's single 512-wide
+// attention head (the reference runs that VAE in fp32, /root/reference/scripts/generate_video_demo.py:171-175).
+extern "C" int sp_gemm_f32out_f16(const void *a_, int64_t lda, const void *w, void *d, int m, int n, int k,
+                                  const void *zero_page, void *stream) {
+  SP_REQUIRE(a_ && w && d && zero_page, "sp_gemm_f32out_f16: null a/w/d/zero_page");
+  SP_REQUIRE(m > 0 && n > 0 && n % 256 == 0, "sp_gemm_f32out_f16: n=%d must be a positive multiple of 256 (m=%d)", n, m);
+  SP_REQUIRE(k >= 64 && k % 64 == 0, "sp_gemm_f32out_f16: k=%d must be a multiple of 64", k);
+  SP_REQUIRE(lda >= k && lda % 8 == 0, "sp_gemm_f32out_f16: lda=%lld invalid", (long long)lda);
+  SP_REQUIRE(((uintptr_t)d & 15) == 0, "sp_gemm_f32out_f16: d must be 16-byte aligned");
+  GemmArgs a{};
+  a.a = (const f16 *)a_; a.w = (const f16 *)w; a.zero = (const char *)zero_page;
+  a.lda = lda; a.mode = SP_A_LINEAR; a.cin = k; a.taps = 1; a.m = m; a.n = n; a.k = k;
+  a.oscale = 1.0f; a.bias2_rows = m; a.ldb2 = n;
+  a.ksplit = 1; a.partial = (float *)d;
+  return spgemm::launch_pp(a, 256, 256, (hipStream_t)stream);
+}
+
 extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   SP_REQUIRE(d != nullptr, "sp_gemm_f16: null descriptor");
   SP_REQUIRE(d->a && d->w && d->d && d->zero_page, "sp_gemm_f16: null a/w/d/zero_page");
@@ -687,11 +706,14 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   a.ln_out = d->ln_out; a.ln_out_eps = d->ln_out_eps;
   a.w_group_rows = 0; a.w_group_stride = 0;
   if (d->w_group_rows != 0) {
+    // (a folded LayerNorm's column sums belong to ONE weight matrix: with one matrix per row group the mean term would be
+    // silently wrong.  A forced route is ignored for grouped weights: only the ping-pong tiles pick a matrix per tile.)
     SP_REQUIRE(d->w_group_rows > 0 && d->w_group_rows % 128 == 0 && d->w_group_stride > 0 && d->w_group_stride % 8 == 0 &&
-                   d->mode == SP_A_LINEAR && !d->geglu && !d->euler_out && (d->n % 256 == 0 || d->n % 320 == 0),
-               "sp_gemm_f16: per-row-group weights need SP_A_LINEAR, no geglu / Euler tail, n a multiple of 256 or 320, "
-               "w_group_rows a positive multiple of 128 (got %lld) and w_group_stride a positive multiple of 8 (got %lld)",
-               (long long)d->w_group_rows, (long long)d->w_group_stride);
+                   d->mode == SP_A_LINEAR && !d->geglu && !d->euler_out && (d->n % 256 == 0 || d->n % 320 == 0) &&
+                   !d->ln_stats && !d->ln_colsum,
+               "sp_gemm_f16: per-row-group weights need SP_A_LINEAR, no geglu / Euler tail / folded LayerNorm (ln_stats), n a "
+               "multiple of 256 or 320, w_group_rows a positive multiple of 128 (got %lld) and w_group_stride a positive multiple "
+               "of 8 (got %lld)", (long long)d->w_group_rows, (long long)d->w_group_stride);
     a.w_group_rows = d->w_group_rows; a.w_group_stride = d->w_group_stride;
   }
   if (d->ln_out) {

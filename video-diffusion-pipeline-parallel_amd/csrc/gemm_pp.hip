@@ -661,7 +661,7 @@ int launch_pp(GemmArgs &a, hipStream_t s) {
 }  // namespace
 
 int launch_pp(GemmArgs &a, int bm, int bn, hipStream_t s) {
-  if (a.ksplit > 1) return launch_pp<256, 256, 128>(a, s);
+  if (a.ksplit >= 1 && a.partial) return launch_pp<256, 256, 128>(a, s);   // raw fp32 sums per K slice (1 slice: sp_gemm_f32out_f16)
 #ifdef SP_GEMM_EXPERIMENTS
   if (bm == 256 && bn == 256) switch (a.dbg) {
     case 1: return launch_pp<256, 256, 1>(a, s);

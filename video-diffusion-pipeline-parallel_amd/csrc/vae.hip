@@ -15,7 +15,62 @@ namespace {
 
 // A score that overflowed fp16 on its way out of the contraction (+-inf) is read as +-65504: the row then has a finite
 // maximum and no inf - inf = NaN; a single saturated score gets (correctly) all of the row's mass.
-__device__ __forceinline__ float finite_f16(f16 h) { return __builtin_amdgcn_fmed3f((float)h, -65504.0f, 65504.0f); }
+// A NaN stays a NaN (an upstream inf - inf must remain visible to decode_latents(check_finite=True)).
+__device__ __forceinline__ float finite_f16(f16 h) {
+  const float f = (float)h;
+  return f != f ? f : __builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f);
+}
+
+// Row softmax of fp32 logits: p = softmax(scale * s) written as fp16.  One workgroup per row, the row in registers (fp32),
+// fp32 statistics; `out` may be the FRONT of the same row (in-place shrink: every thread holds its logits in registers
+// before the first probability is written -- the two barriers of the reductions lie between).  Nothing is clamped: the
+// logits never passed through fp16, and a NaN stays a NaN.
+template <int MAXV>
+__global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float *__restrict__ x, int64_t ld, f16 *__restrict__ out,
+                                                               int64_t ldo, int cols, float scale_log2e) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *row = x + (int64_t)blockIdx.x * ld;
+  f16 *orow = out + (int64_t)blockIdx.x * ldo;
+  const int oc = cols >> 2;                       // 16-byte pieces of four logits
+  f32x4 v[MAXV];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int o = tid + i * 256;
+    if (o < oc) {
+      v[i] = *(const f32x4 *)(row + o * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, v[i][e]);
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float nm = -mx * scale_log2e;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int o = tid + i * 256;
+    if (o < oc) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[i][e] = __builtin_amdgcn_exp2f(fmaf(v[i][e], scale_log2e, nm)); s += v[i][e]; }
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[4 + wave] = s;
+  __syncthreads();
+  const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));     // fixed order: deterministic
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int o = tid + i * 256;
+    if (o < oc) {
+      const f16x4 w = {(f16)(v[i][0] * inv), (f16)(v[i][1] * inv), (f16)(v[i][2] * inv), (f16)(v[i][3] * inv)};
+      *(f16x4 *)(orow + o * 4) = w;
+    }
+  }
+}
 
 template <int MAXV>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(f16 *__restrict__ x, int64_t ld, int cols) {
@@ -156,6 +211,32 @@ extern "C" int sp_softmax_rows_f16(void *x, int64_t ld, int64_t rows, int cols, 
   else
     hipLaunchKernelGGL(softmax_rows_kernel<8>, dim3((unsigned)rows), dim3(256), 0, s, (f16 *)x, ld, cols);
   SP_CHECK_LAUNCH("sp_softmax_rows_f16");
+  return SP_OK;
+}
+
+extern "C" int sp_softmax_rows_f32(const float *x, int64_t ld, void *out, int64_t ldo, int64_t rows, int cols, float scale,
+                                   void *stream) {
+  SP_REQUIRE(x && out, "sp_softmax_rows_f32: null pointer");
+  SP_REQUIRE(rows > 0 && rows <= 0x7fffffff && cols >= 4 && cols % 4 == 0 && cols <= 4 * 256 * 16 && ld >= cols && ld % 4 == 0 &&
+                 ldo >= cols && ldo % 4 == 0,
+             "sp_softmax_rows_f32: rows=%lld cols=%d ld=%lld ldo=%lld unsupported (cols a multiple of 4, <= 16384)",
+             (long long)rows, cols, (long long)ld, (long long)ldo);
+  // in place = the probabilities of row r overwrite the front of row r's logits: rows must not overlap other rows' logits
+  SP_REQUIRE((const void *)x != (const void *)out || ldo == 2 * ld,
+             "sp_softmax_rows_f32: in place needs ldo == 2 * ld (fp16 row pitch in halves = fp32 row pitch in bytes / 2)");
+  hipStream_t s = (hipStream_t)stream;
+  const int oc = cols / 4;
+  const float sl = scale * 1.4426950408889634f;
+  SP_CLEAR_STALE_ERROR();
+  if (oc <= 256 * 2)
+    hipLaunchKernelGGL(softmax_rows_f32_kernel<2>, dim3((unsigned)rows), dim3(256), 0, s, x, ld, (f16 *)out, ldo, cols, sl);
+  else if (oc <= 256 * 5)
+    hipLaunchKernelGGL(softmax_rows_f32_kernel<5>, dim3((unsigned)rows), dim3(256), 0, s, x, ld, (f16 *)out, ldo, cols, sl);
+  else if (oc <= 256 * 9)
+    hipLaunchKernelGGL(softmax_rows_f32_kernel<9>, dim3((unsigned)rows), dim3(256), 0, s, x, ld, (f16 *)out, ldo, cols, sl);
+  else
+    hipLaunchKernelGGL(softmax_rows_f32_kernel<16>, dim3((unsigned)rows), dim3(256), 0, s, x, ld, (f16 *)out, ldo, cols, sl);
+  SP_CHECK_LAUNCH("sp_softmax_rows_f32");
   return SP_OK;
 }
 

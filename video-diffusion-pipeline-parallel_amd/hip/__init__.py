@@ -71,6 +71,8 @@ SIGNATURES = {
     "sp_concat_channels_f16": (_I, [_P, _I, _P, _I, _P, _L, _P]),
     "sp_add_rowvec_f16": (_I, [_P, _P, _P, _L, _I, _P]),
     "sp_softmax_rows_f16": (_I, [_P, _L, _L, _I, _P]),
+    "sp_gemm_f32out_f16": (_I, [_P, _L, _P, _P, _I, _I, _I, _P, _P]),
+    "sp_softmax_rows_f32": (_I, [_P, _L, _P, _L, _L, _I, _F, _P]),
     "sp_vae_pack_latent_f16": (_I, [_P, _P, _F, _L, _I, _I, _L, _L, _L, _I, _I, _I, _P]),
     "sp_vae_frames_out_f16": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _L, _L, _P]),
     "sp_vae_image_pack_f16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -283,6 +283,35 @@ def softmax_rows(x, *, rows, cols, ld=None):
     return x
 
 
+def gemm_f32out(a, w, out32, *, m, n, k, lda=None):
+    """``out32[m][n]`` (fp32, contiguous) = ``a[m][k] @ w[n][k]^T`` as raw fp32 sums (``sp_gemm_f32out_f16``): logits that
+    must not pass through fp16 on their way into a softmax.  n a multiple of 256, k of 64."""
+    lda = int(lda if lda is not None else a.stride(0))
+    _f16(a, "a"); _f16(w, "w")
+    if out32.dtype != torch.float32 or not out32.is_cuda or not out32.is_contiguous() or out32.numel() < m * n:
+        raise TypeError("out32 must be a contiguous float32 HIP tensor of at least m*n elements")
+    if w.dim() == 2 and w.shape[0] > 1 and w.stride(0) != k:
+        raise ValueError(f"w: row stride {w.stride(0)} must equal k = {k}")
+    with _Timed("gemm_f32out", 2.0 * m * n * k, 2.0 * (m * k + n * k) + 4.0 * m * n):
+        _check(load().sp_gemm_f32out_f16(a.data_ptr(), lda, w.data_ptr(), out32.data_ptr(), m, n, k,
+                                         zero_page(a.device).data_ptr(), _stream()), "sp_gemm_f32out_f16")
+    return out32
+
+
+def softmax_rows_f32(x32, out16, *, rows, cols, scale=1.0, ld=None, ldo=None):
+    """``out16[r][:cols] = fp16(softmax(scale * x32[r][:cols]))``, fp32 logits in, fp32 statistics (``sp_softmax_rows_f32``).
+    ``out16`` may be a float16 VIEW of ``x32`` itself (``x32.view(torch.float16)``, row pitch 2*ld halves): the
+    probabilities then overwrite the front of each row's logits."""
+    ld = int(ld if ld is not None else x32.stride(0))
+    ldo = int(ldo if ldo is not None else out16.stride(0))
+    if x32.dtype != torch.float32 or not x32.is_cuda or out16.dtype != torch.float16 or not out16.is_cuda:
+        raise TypeError("x32 must be float32 and out16 float16, both on a HIP device")
+    with _Timed("softmax_rows", 0.0, (4.0 + 2.0) * rows * cols):
+        _check(load().sp_softmax_rows_f32(x32.data_ptr(), ld, out16.data_ptr(), ldo, rows, cols, float(scale), _stream()),
+               "sp_softmax_rows_f32")
+    return out16
+
+
 def video_strides(t, layout):
     """(sb, sc, sf) element strides of a contiguous video tensor: "bcfhw" = (B,C,F,H,W), "nchw" = (B*F,C,H,W)."""
     if layout == "bcfhw":

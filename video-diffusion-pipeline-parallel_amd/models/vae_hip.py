@@ -17,8 +17,10 @@ from the implicit-GEMM kernel instead of a dedicated flash kernel -- per frame `
 weight operand), an in-place row softmax (``sp_softmax_rows_f16``), ``V^T = W_v X^T`` (so that V^T is a K-contiguous
 weight operand) and ``O = P V^T^T + b_v`` (rows of P sum to one, so the value bias moves behind the product).  The
 score matrix of one frame (170 MB at 9,216 tokens) is the only large scratch and is reused frame after frame.
-Scores pass through fp16 between the two products (a fused head_dim-512 kernel would keep them in fp32): stated in
-DESIGN.md.
+Since round 5 the logits stay fp32 into the softmax wherever a frame has a multiple of 256 tokens
+(``sp_gemm_f32out_f16`` + ``sp_softmax_rows_f32``, the probabilities overwrite the front of each row's logits), so that
+trained weights whose logits exceed fp16's range or precision are handled the way the reference's fp32 upcast handles them;
+other token counts keep fp16 scores with a saturating softmax.
 
 Precision: fp16 storage / fp32 accumulation throughout.  The reference upcasts this VAE to fp32
 (``force_upcast``, ``generate_video_demo.py:171-175``) because fp16 activations of the trained decoder can overflow;
@@ -197,6 +199,9 @@ class _VAEKernels:
         if any(v % 64 for v in cfg.block_out_channels):
             raise ValueError("block_out_channels must be multiples of 64 (MFMA K-steps)")
         self._ws = {}
+        # mid-block attention logits in fp32 wherever the token count allows (a multiple of 256); VDPP_VAE_FP16_SCORES=1
+        # selects the round-3 composition with fp16 scores everywhere (A/B, tests)
+        self.fp32_scores = __import__("os").environ.get("VDPP_VAE_FP16_SCORES") != "1"
         return dev
 
     def _attn(self, sd, p, c):
@@ -239,16 +244,32 @@ class _VAEKernels:
         q = self._gemm(p["q"], t, m)
         k = self._gemm(p["k"], t, m)
         o = self._buf(m, c)
-        scores = self._buf(hw, hw)
         vt = self._buf(c, hw)
         scale = 1.0 / math.sqrt(c)
-        for i in range(n_img):
-            r = slice(i * hw, (i + 1) * hw)
-            ops.gemm(q[r], k[r], scores, m=hw, n=hw, cin=c, oscale=scale)                 # S = Q K^T / sqrt(C)
-            ops.softmax_rows(scores, rows=hw, cols=hw)
-            ops.gemm(p["wv"], t[r], vt, m=c, n=hw, cin=c)                                 # V^T = W_v X^T   [C][tokens]
-            ops.gemm(scores, vt, o[r], m=hw, n=c, cin=hw, bias=p["bv"])                    # O = P V + b_v
-        del scores, vt, q, k, t
+        if hw % 256 == 0 and c % 64 == 0 and self.fp32_scores:
+            # Logits in fp32 all the way into the softmax (round 5; the reference runs this VAE in fp32 because trained
+            # weights overflow fp16, generate_video_demo.py:171-175): Q K^T leaves the contraction as raw fp32 sums, the
+            # softmax scales, normalises and writes the fp16 probabilities over the front of each row's logits, and the
+            # second contraction reads them with twice the row pitch.  No logit is ever rounded to fp16 or clamped.
+            scores32 = torch.empty((hw, hw), dtype=torch.float32, device=self.device)
+            probs = scores32.view(torch.float16)                                          # [hw][2*hw] halves, same memory
+            for i in range(n_img):
+                r = slice(i * hw, (i + 1) * hw)
+                ops.gemm_f32out(q[r], k[r], scores32, m=hw, n=hw, k=c)                    # S = Q K^T (fp32)
+                ops.softmax_rows_f32(scores32, probs, rows=hw, cols=hw, scale=scale, ld=hw, ldo=2 * hw)
+                ops.gemm(p["wv"], t[r], vt, m=c, n=hw, cin=c)                             # V^T = W_v X^T   [C][tokens]
+                ops.gemm(probs[:, :hw], vt, o[r], m=hw, n=c, cin=hw, lda=2 * hw, bias=p["bv"])   # O = P V + b_v
+            del scores32, probs
+        else:                                   # token counts the fp32-output tiles do not cover: fp16 scores (saturating)
+            scores = self._buf(hw, hw)
+            for i in range(n_img):
+                r = slice(i * hw, (i + 1) * hw)
+                ops.gemm(q[r], k[r], scores, m=hw, n=hw, cin=c, oscale=scale)             # S = Q K^T / sqrt(C)
+                ops.softmax_rows(scores, rows=hw, cols=hw)
+                ops.gemm(p["wv"], t[r], vt, m=c, n=hw, cin=c)                             # V^T = W_v X^T   [C][tokens]
+                ops.gemm(scores, vt, o[r], m=hw, n=c, cin=hw, bias=p["bv"])                # O = P V + b_v
+            del scores
+        del vt, q, k, t
         return self._gemm(p["out"], o, m, res1=x, r1scale=1.0)
 
 
