@@ -741,6 +741,36 @@ def test_config5_shape_fp8_attention_agrees_with_fp16():
     assert 0 < err <= 3e-2, f"fp8 attention route off at the config-5 shape: rel_l2={err:.3e}"
 
 
+def test_feed_forward_pairs_in_row_chunks_are_bit_identical():
+    """SVDUNetHIP.FF_CHUNK_BYTES (VDPP_FF_CHUNK_MB): FF1 -> GEGLU -> FF2 run chunk of rows by chunk of rows, so that the hidden
+    activation of a chunk is still in the Infinity Cache when FF2 reads it.  Chunks start on tile boundaries, every tile
+    computes what it computed before: the forward must not change by a bit -- including the LayerNorm row statistics
+    that the chunked FF2 leaves for the next contraction (t_fi2 -> temporal Q/K/V)."""
+    from vdpp_amd.models.unet_hip import SVDUNetHIP
+    cfg, sd, ref, hip = _build(c=256, seed=47)               # 256 channels: the row statistics come out of the epilogues
+    g = torch.Generator().manual_seed(3)
+    sample = torch.randn(2, 3, 8, 16, 16, generator=g).half().to(DEV)
+    ctx = torch.randn(2, 1, cfg.cross_attention_dim, generator=g).half().to(DEV)
+    ids = torch.tensor([[5.0, 127.0, 0.02]] * 2).to(DEV)
+    want = hip(sample, 0.6, ctx, ids)[0]
+    calls = []
+    orig = SVDUNetHIP._gemm
+
+    def counting(self, r, layer, a, **kw):
+        calls.append((layer.geglu, kw.get("m")))
+        return orig(self, r, layer, a, **kw)
+
+    hip.FF_CHUNK_BYTES, hip.FF_CHUNK_ROUND = 1 << 18, 256
+    try:
+        SVDUNetHIP._gemm = counting
+        got = hip(sample, 0.6, ctx, ids)[0]
+    finally:
+        SVDUNetHIP._gemm = orig
+        hip.FF_CHUNK_BYTES, hip.FF_CHUNK_ROUND = 0, None
+    assert any(geglu and m is not None and m < 2 * 3 * 256 for geglu, m in calls), "no feed-forward was chunked"
+    assert torch.equal(got, want)
+
+
 def test_from_pretrained_local_directory(tmp_path):
     """from_pretrained on a LOCAL diffusers-style directory (unet/config.json + *.safetensors) builds the same
     network as handing the state_dict over directly."""

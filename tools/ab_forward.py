@@ -3,7 +3,7 @@
 them in flight on two HIP streams): the arms alternate for ROUNDS rounds, best and median ms per video and forward.
 usage: ab_forward.py [--lib exp] [--rounds 5] [--steps 6] ARM ARM ...
 ARM = comma-separated settings: env:NAME=VALUE (process environment, e.g. env:SP_GEMM_DBG=256 with --lib exp) or
-      unet:ATTR=0|1 (attribute of the SVDUNetHIP engine, e.g. unet:fold_groupnorm=0, unet:long_attention=0) or
+      unet:ATTR=0|1|INT (attribute of the SVDUNetHIP engine, e.g. unet:fold_groupnorm=0, unet:FF_CHUNK_BYTES=176160768) or
       route:R=BM (sp_gemm_set_route(R, BM, 0) for the whole forward, e.g. route:2=0 = ping-pong kernels only); "base" = nothing."""
 import argparse, os, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -49,7 +49,7 @@ def apply(arm):
             hip.load().sp_gemm_set_route(int(name), int(val), 0)
         elif kind == "unet":
             defaults.setdefault(name, getattr(model.unet, name))
-            setattr(model.unet, name, bool(int(val)))
+            setattr(model.unet, name, bool(int(val)) if val in ("0", "1") else int(val))
         else:
             raise SystemExit(f"unknown setting {item}")
 

@@ -525,7 +525,7 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
   PP_TRACE_CLK(8);
 
 #ifdef SP_GEMM_EXPERIMENTS
-  constexpr int dbg = EXP;   // timing experiments only: 1 no DMA in loop, 2 no MFMA, 4 DMA between MFMAs, 64 no ds_read
+  constexpr int dbg = EXP;   // timing experiments only: 1 no DMA in loop, 2 no MFMA, 4 DMA between MFMAs, 64 no ds_read, 32 GroupNorm+SiLU on the A fragments
   constexpr bool DMA_IN_COMPUTE = (dbg & 4) != 0;
 #endif
   for (int kt = 0; kt < nk; ++kt) {
@@ -551,6 +551,26 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
 #pragma unroll
       for (int j = 0; j < TM; ++j) fa[j] = *(const f16x8 *)(sa + offa[j]);
     }
+#ifdef SP_GEMM_EXPERIMENTS
+    if constexpr ((dbg & 32) != 0) {
+      // timing only: GroupNorm apply + SiLU in the CONSUMER's A path -- y = silu(x * scale + shift)
+      // on every activation fragment after its ds_read, in packed fp16 (the cheapest form: 4 packed ops + 4 half-rate
+      // transcendentals per pair); scale / shift per channel would come from LDS, here they are lane constants.  Results
+      // are wrong (and out-of-image taps would have to stay zero): the arm prices the instruction stream only.
+      const f16x2 sc2 = {(f16)(1.0f + 0.001f * lane), (f16)1.0f}, sh2 = {(f16)0.01f, (f16)(0.002f * lane)};
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f16x2 v = {fa[j][2 * e], fa[j][2 * e + 1]};
+          v = __builtin_elementwise_fma(v, sc2, sh2);
+          const f16x2 t = __builtin_elementwise_exp2(v * (f16x2){(f16)-1.4427f, (f16)-1.4427f}) + (f16x2){(f16)1.0f, (f16)1.0f};
+          v = v * (f16x2){(f16)__builtin_amdgcn_rcph(t[0]), (f16)__builtin_amdgcn_rcph(t[1])};
+          fa[j][2 * e] = v[0]; fa[j][2 * e + 1] = v[1];
+        }
+      }
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #ifdef SP_GEMM_EXPERIMENTS
     if constexpr (DMA_IN_COMPUTE) {
@@ -679,6 +699,7 @@ int launch_pp(GemmArgs &a, int bm, int bn, hipStream_t s) {
     if (bm == 256 && bn == 320) return launch_pp<256, 320, 16>(a, s);
     if (bm == 192 && bn == 256) return launch_pp<192, 256, 16>(a, s);
   }
+  if (a.dbg == 32 && bm == 256 && bn == 320) return launch_pp<256, 320, 32>(a, s);
   if (a.dbg == 8) {
     if (bm == 256 && bn == 256) return launch_pp<256, 256, 8>(a, s);
     if (bm == 256 && bn == 320) return launch_pp<256, 320, 8>(a, s);

@@ -369,9 +369,9 @@ class SVDUNetHIP:
                       w_group_stride=w_groups[0].shape[1] * w_groups[0].shape[2])
         st = None
         ws = r.sk_ws if m <= self.SPLITK_MAX_ROWS else None
-        if ln_next is not None and layer.n_true in (256, 320, 512, 640) and layer.n == layer.n_true and not layer.geglu \
-                and "euler" not in kw:
-            st = torch.empty((m, 2), dtype=torch.float32, device=self.device)
+        st_buf = kw.pop("ln_out_buf", None)             # caller-provided rows of a larger statistics tensor (_ff_pair chunks)
+        if ln_next is not None and self._ln_out_ok(layer) and "euler" not in kw:
+            st = st_buf if st_buf is not None else torch.empty((m, 2), dtype=torch.float32, device=self.device)
             kw.update(ln_out=st, ln_out_eps=ln_next.ln_eps)
             ws = torch.empty((m, 4), dtype=torch.float32, device=self.device) if layer.n_true > 320 else None
         if out is None:
@@ -390,11 +390,16 @@ class SVDUNetHIP:
         ops.gemm(a, weight, out, m=m, n=layer.n, cin=layer.cin, mode=layer.mode, conv=conv, temporal=temporal,
                  bias=bias, geglu=layer.geglu, n_store=n_store, ldd=out.stride(0), lda=a.stride(0),
                  ln_colsum=layer.colsum, workspace=ws, **kw)
-        if st is not None:
+        if st is not None and st_buf is None:
             # valid for exactly this tensor object in exactly this state (checked in _ln_stats): a view, a slice or an
             # in-place write after the contraction silently falls back to the statistics pass
             out._row_ln_stats = (st, ln_next.ln_eps, out.data_ptr(), _version(out), tuple(out.shape))
         return out
+
+    @staticmethod
+    def _ln_out_ok(layer: _Dense) -> bool:
+        """Can this contraction's epilogue leave the next LayerNorm's row statistics (a row = one or two tiles)?"""
+        return layer.n_true in (256, 320, 512, 640) and layer.n == layer.n_true and not layer.geglu
 
     def _ln_stats(self, layer: _Dense, x, **kw):
         """(mean, rstd) per row of x for the LayerNorm folded into ``layer``."""
@@ -498,14 +503,48 @@ class SVDUNetHIP:
         t = self._gn(r, p["norm"], x, temporal=False, silu=False)
         return self._gemm(r, p["pin"], t, ln_next=p["s_attn"]["qkv"])
 
+    # GEGLU feed-forward pairs in row chunks (VDPP_FF_CHUNK_MB, default 0 = whole tensor): the hidden activation of a
+    # level-0 / level-1 feed-forward (660 / 330 MB for two videos) is written by FF1 and read once by FF2; cut into row
+    # chunks whose hidden slice fits the 256 MiB Infinity Cache with room to spare, FF2 finds it there instead of in HBM.
+    # Chunks are whole rounds of 256-row FF2 tiles (256 tiles x tiles_n) so that no round of workgroups is cut short.
+    FF_CHUNK_BYTES = int(os.environ.get("VDPP_FF_CHUNK_MB", "0")) << 20
+    FF_CHUNK_ROUND = None            # tests: rows a chunk is rounded to (default: one full round of FF2 workgroups)
+
+    def _ff_pair(self, r: _Run, ff1: _Dense, ff2: _Dense, x, st, **epi):
+        """``ff2(geglu(ff1(LN(x))))`` with ff2's epilogue arguments ``epi`` (residuals are row-sliced along)."""
+        m, hid = x.shape[0], ff1.n_true
+        budget = self.FF_CHUNK_BYTES
+        if not budget or m * hid * 2 <= budget:
+            g = self._gemm(r, ff1, x, ln_stats=st)
+            return self._gemm(r, ff2, g, **epi)
+        tiles_n = max(1, ff2.n // 320 if ff2.n % 320 == 0 else ff2.n // 256)
+        rows_round = self.FF_CHUNK_ROUND or 256 * max(1, 256 // tiles_n)   # rows of one full round of FF2 workgroups
+        rows = max(rows_round, (budget // (hid * 2)) // rows_round * rows_round)
+        out = epi.pop("out", None)
+        if out is None:
+            out = self._buf(m, ff2.n_true)
+        ln_next = epi.pop("ln_next", None)
+        st_next = None
+        if ln_next is not None and self._ln_out_ok(ff2):
+            st_next = torch.empty((m, 2), dtype=torch.float32, device=self.device)
+        for r0 in range(0, m, rows):
+            r1 = min(m, r0 + rows)
+            kw = {k: (v[r0:r1] if k in ("res1", "res2") and v is not None else v) for k, v in epi.items()}
+            if st_next is not None:
+                kw.update(ln_next=ln_next, ln_out_buf=st_next[r0:r1])
+            g = self._gemm(r, ff1, x[r0:r1], m=r1 - r0, ln_stats=st[r0:r1])
+            self._gemm(r, ff2, g, m=r1 - r0, out=out[r0:r1], **kw)
+            del g
+        if st_next is not None:
+            out._row_ln_stats = (st_next, ln_next.ln_eps, out.data_ptr(), _version(out), tuple(out.shape))
+        return out
+
     def _run_transformer(self, r: _Run, p, x, out=None):
         c, a = p["c"], p["alpha"]
         hs = self._proj_in(r, p, x)
         # --- spatial block
         hs1 = self._self_attn(r, p["s_attn"], p["s_x"], hs, temporal=False, ln_next=p["s_ff1"])
-        g = self._gemm(r, p["s_ff1"], hs1, ln_stats=self._ln_stats(p["s_ff1"], hs1))
-        hs_s = self._gemm(r, p["s_ff2"], g, res1=hs1, r1scale=1.0)
-        del g
+        hs_s = self._ff_pair(r, p["s_ff1"], p["s_ff2"], hs1, self._ln_stats(p["s_ff1"], hs1), res1=hs1, r1scale=1.0)
         # --- frame positional embedding (B*F rows)
         pe = r.pos[c][p["pos_idx"]]
         if r.b > 1:
@@ -513,14 +552,12 @@ class SVDUNetHIP:
         # --- temporal block on hmix = hs_s + pe[frame]
         hmix = self._buf(r.m, c)
         st = self._ln_stats(p["t_fi1"], hs_s, addvec=pe, addvec_rows=r.hw, sum_out=hmix)   # also writes hmix = hs_s + pe
-        g = self._gemm(r, p["t_fi1"], hmix, ln_stats=st)
-        ht = self._gemm(r, p["t_fi2"], g, res1=hmix, r1scale=1.0, ln_next=p["t_attn"]["qkv"])
-        del g, hmix, st
+        ht = self._ff_pair(r, p["t_fi1"], p["t_fi2"], hmix, st, res1=hmix, r1scale=1.0, ln_next=p["t_attn"]["qkv"])
+        del hmix, st
         ht1 = self._self_attn(r, p["t_attn"], p["t_x"], ht, temporal=True, ln_next=p["t_ff1"])
-        g = self._gemm(r, p["t_ff1"], ht1, ln_stats=self._ln_stats(p["t_ff1"], ht1))
         # temporal out = ff(..)+ht1 ; blend = a*hs_s + (1-a)*temporal out   (folded into the epilogue)
-        mix = self._gemm(r, p["t_ff2"], g, oscale=1.0 - a, res1=ht1, r1scale=1.0 - a, res2=hs_s, r2scale=a)
-        del g
+        mix = self._ff_pair(r, p["t_ff1"], p["t_ff2"], ht1, self._ln_stats(p["t_ff1"], ht1), oscale=1.0 - a, res1=ht1,
+                            r1scale=1.0 - a, res2=hs_s, r2scale=a)
         return self._gemm(r, p["pout"], mix, res1=x, r1scale=1.0, out=out)
 
     # ------------------------------------------------------------------ forward
