@@ -305,22 +305,50 @@ __global__ __launch_bounds__(256, 1) void attn_long_kernel(
 #pragma unroll
       for (int s = 0; s < 4; ++s) kf[kt][s] = *(const f16x8 *)(sk + koff[kt] + (((2 * s + hq) ^ kswz) << 4));
   };
-  auto steady2 = [&](int i, int buf) {
+  // Per-tile addresses are LOOP-CARRIED (round 5): the global addresses of visit i+2's K / V tile, its tile index, the
+  // LDS offsets of the three ring slots in their roles (tile being consumed / next / free = the one visit i+2 lands in)
+  // and the V read addresses.  Round 4 derived them from (i, buf) at the top of every tile -- 42 scalar instructions with
+  // two 64-bit multiplies between the last MFMA of one tile and the first of the next, ~200 of the tile's 2,000 cycles
+  // with the matrix pipe idle (in-kernel stamps).  Now the next tile's values are produced by a few scalar adds UNDER
+  // the MFMAs of row 10, where the vector pipe has nothing to do either.
+  const char *kb2 = nullptr, *vb2 = nullptr;
+  int tl2 = 0, o_cur = 0, o_nxt = 0, o_prv = 0;
+  unsigned va[2] = {0u, 0u};
+  const int kstep32 = (int)kstep, vstep32 = (int)vstep;          // (host contract: 5 tiles of K / V rows fit 31 bits)
+  auto lds_addr = [&](int off) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)(smem + off); };
+  auto steady_setup = [&](int i, int buf) {                       // once, in front of the steady loop
+    const int vis = i + 2 < ntiles ? i + 2 : ntiles - 1;
+    tl2 = vis < OWN ? own0 + vis : (vis - OWN < own0 ? vis - OWN : vis);
+    kb2 = kbase + tl2 * kstep; vb2 = vbase + tl2 * vstep;
+    o_cur = buf * STAGE;
+    o_nxt = (buf + 1 == RING ? 0 : buf + 1) * STAGE;
+    o_prv = (buf >= 1 ? buf - 1 : RING - 1) * STAGE;              // slot of visit i-1 = (i+2) % 3
+    va[0] = lds_addr(o_cur + K_BYTES) + vlane0; va[1] = lds_addr(o_cur + K_BYTES) + vlane1;
+  };
+  auto steady2 = [&](int i) {
     static_assert(QB == 2, "the written-out schedule is for two query blocks");
     // The four LDS-DMA pieces of visit i+2 are issued one at a time between the rows: back to back at the top of the
     // tile (all four waves at once, right after the barrier) they queue up behind each other in the texture path and
     // the issuing wave -- alone on its SIMD -- stands still for ~540 cycles per tile (tools/trace_attn_long.py).
     // Past the end the last tile is fetched again into the free slot: no branch in the tile, one uniform vmcnt.
-    const int vis = i + 2 < ntiles ? i + 2 : ntiles - 1;
-    const int tl2 = vis < OWN ? own0 + vis : (vis - OWN < own0 ? vis - OWN : vis);
-    const char *kb2 = kbase + tl2 * kstep, *vb2 = vbase + tl2 * vstep;
-    char *sk2 = smem + (buf >= 1 ? buf - 1 : RING - 1) * STAGE;   // slot of visit i-1 = (i+2) % 3
+    char *sk2 = smem + o_prv;
     auto dma = [&](int j, bool v_piece) {
       if (v_piece) glds16(vb2 + vofl[j], sk2 + K_BYTES + (wave * 16 + j * 8) * 128);
       else glds16(kb2 + kofl[j], sk2 + (wave * 16 + j * 8) * 128);
     };
-    const char *sk = smem + buf * STAGE;
-    const char *sv = sk + K_BYTES;
+    // the next tile's addresses (i >= WARM > OWN: visits past the own tiles; tile index steps by 1, by 1 + OWN across this
+    // workgroup's own tiles, by 0 once the walk is clamped at the last tile)
+    auto advance_global = [&]() {
+      const int visn = i + 3 < ntiles ? i + 3 : ntiles - 1;
+      const int tln = visn - OWN < own0 ? visn - OWN : visn;
+      const int d = tln - tl2;
+      kb2 += (unsigned)(d * kstep32); vb2 += (unsigned)(d * vstep32);
+      tl2 = tln;
+    };
+    auto advance_slots = [&]() {
+      const int t = o_prv; o_prv = o_cur; o_cur = o_nxt; o_nxt = t;
+      va[0] = lds_addr(o_cur + K_BYTES) + vlane0; va[1] = lds_addr(o_cur + K_BYTES) + vlane1;
+    };
     f32x16 sc[2][2];                         // [block][key half]
     unsigned pw[2][2][2][4];                 // [block][key half][8 scores][pair]: scalars, so that no pass merges the converts
     u32x2 vr[2][8];
@@ -355,14 +383,12 @@ __global__ __launch_bounds__(256, 1) void attn_long_kernel(
     // LDS reads one or two per step as well (four waves reading a tile's 8 KB of K or V at the same moment wait on each
     // other for ~250 cycles): V fragments of keys 0-31 under row 4, of keys 32-63 under row 5 (they take the registers
     // the K fragments leave), the next tile's K fragments under rows 8-10
-    const unsigned va[2] = {(unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)(sv + vlane0),
-                            (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)(sv + vlane1)};
     auto RV = [&](int j) {                                       // (inline asm: for the builtin hipcc waits for the LDS-DMA in flight)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[dt][j]) : "v"(va[dt]), "n"(j * 8 * 128) : "memory");
     };
-    const char *skn = smem + (buf + 1 == RING ? 0 : buf + 1) * STAGE;
+    const char *skn = smem + o_nxt;
     auto RK = [&](int n) { kf[n >> 2][n & 3] = *(const f16x8 *)(skn + koff[n >> 2] + (((2 * (n & 3) + hq) ^ kswz) << 4)); };
     // row 1
 #pragma unroll
@@ -414,12 +440,13 @@ __global__ __launch_bounds__(256, 1) void attn_long_kernel(
     ROW(1, 0, 1, 1, 1, RK(3), RK(4), RK(5))
 #undef ROW
     STAMP(7);
-    // row 10
+    // row 10 (matrix pipe only): the next tile's addresses are produced under its MFMAs
     P(1, 1, 0, 0); RK(6); SB();
     P(1, 1, 0, 1); RK(7); SB();
-    P(1, 1, 0, 2); SB();
-#pragma unroll
-    for (int w = 0; w < 3; ++w) { P(1, 1, 1, w); SB(); }
+    P(1, 1, 0, 2); advance_global(); SB();
+    P(1, 1, 1, 0); SB();
+    P(1, 1, 1, 1); advance_slots(); SB();
+    P(1, 1, 1, 2); SB();
     STAMP(8);
 #undef SB
 #undef STAMP
@@ -443,10 +470,8 @@ __global__ __launch_bounds__(256, 1) void attn_long_kernel(
 #ifdef LONG_TRACE
   const unsigned long long tc0 = __builtin_amdgcn_s_memtime(), tw0 = wall_clock64();
 #endif
-  for (int i = WARM; i < ntiles; ++i) {
-    steady2(i, buf);
-    buf = buf + 1 == RING ? 0 : buf + 1;
-  }
+  steady_setup(WARM, buf);
+  for (int i = WARM; i < ntiles; ++i) steady2(i);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched last tile (steady2) is still on its way into LDS
 
 #ifdef LONG_TRACE
@@ -521,7 +546,8 @@ extern "C" int sp_attn_spatial_long_f16(const void *q, const void *k, const void
              "sp_attn_spatial_long_f16: workspace of %lld bytes, need %lld (4-byte aligned)", (long long)workspace_bytes,
              (long long)need);
   // the LDS-DMA pieces carry 32-bit lane offsets from the tile's base: 64 rows of K / V must fit
-  SP_REQUIRE(64 * ldk * 2 < (1ll << 31) && 64 * ldv * 2 < (1ll << 31), "sp_attn_spatial_long_f16: row stride too large");
+  // (the tile walk advances its K / V addresses by up to five tiles at a time with 32-bit arithmetic)
+  SP_REQUIRE(5 * 64 * ldk * 2 < (1ll << 31) && 5 * 64 * ldv * 2 < (1ll << 31), "sp_attn_spatial_long_f16: row stride too large");
   hipStream_t s = (hipStream_t)stream;
   unsigned *flags = (unsigned *)workspace;
   if (hipMemsetAsync(flags, 0, (size_t)need, s) != hipSuccess) {
