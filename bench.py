@@ -1223,7 +1223,7 @@ def main():
         # The line carries that commit and the algorithmic bytes (every operand / output / residual element once,
         # measured from this run's launches) so that the over-fetch ratio can be read off directly.
         traffic, traffic_src, traffic_commit = None, None, None
-        for name in ("r04_pmc_traffic.json", "r03n_pmc_traffic.json", "r03k_pmc_traffic.json", "r03i_pmc_traffic.json", "r03f_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03n_pmc_traffic.json", "r03k_pmc_traffic.json", "r03i_pmc_traffic.json", "r03f_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pj.get("micro_batch", 1) != mb:      # bytes per launch scale with the videos per UNet call
@@ -1236,7 +1236,7 @@ def main():
         # The clock the chip holds inside these K loops (2.4 GHz nominal is what the 2.5 PFLOP/s peak assumes) comes from
         # in-kernel stamps of the experiments build (tools/clock_in_kernel.py): a static record too.
         clock = None
-        for name in ("r04_clock_in_kernel.json",):
+        for name in ("r05_clock_in_kernel.json", "r04_clock_in_kernel.json"):
             try:
                 clock = json.load(open(os.path.join(ROOT, "profiles", name)))
                 break
