@@ -112,6 +112,14 @@ typedef struct sp_gemm_desc {
      bias2 row per group).  w_group_rows must be a multiple of 128 (no tile may straddle two groups); the call runs on the
      ping-pong kernels (no split-K).  0 = one weight matrix for every row. */
   int64_t w_group_rows; int64_t w_group_stride;
+  /* GroupNorm statistics of the NEXT norm out of this contraction's epilogue (round 5): gn_part = fp32
+     [m/256][2][n][2] -- for every 256-row tile, each of its two 128-row halves and every output column, (sum, sum of
+     squares) of the fp32 output values of the half's rows (bias / bias2 included, before the rounding to fp16).
+     sp_groupnorm_tile_sums_f16 folds them into the (mean, rstd) of any instance that is a whole number of tiles and
+     normalises d without a statistics pass over it.  Needs m a multiple of 256, n a multiple of 256 or 320, no geglu /
+     residuals / folded LayerNorm / ln_out / n_store / Euler tail; the call runs on the 256-row ping-pong tiles.  Sums
+     are folded in a fixed order (bit-reproducible).  NULL = off. */
+  float *gn_part;
 } sp_gemm_desc;
 
 int sp_gemm_f16(const sp_gemm_desc *desc, void *stream);
@@ -168,6 +176,14 @@ int sp_groupnorm_ld_f16(const void *x, int64_t ldx, const float *gamma, const fl
                         int64_t rows, int c, int groups, float eps, int fuse_silu, void *ws,
                         size_t ws_bytes, void *stream);
 
+/* GroupNorm(+SiLU) of a tensor whose producer left per-tile column sums (sp_gemm_desc.gn_part, `part` = that buffer for
+ * the [instances*rows][c] tensor x with c = the producer's n): one small kernel folds the sums of every instance's tiles
+ * into (mean, rstd) per (instance, group) in fp64 (fixed order), then the apply pass of sp_groupnorm_f16 runs -- no
+ * statistics pass over x.  rows must be a multiple of 256 (an instance = whole tiles).  stats: fp32 scratch of
+ * instances*groups*2 floats. */
+int sp_groupnorm_tile_sums_f16(const void *x, int64_t ldx, const float *part, const float *gamma, const float *beta, void *y,
+                               int instances, int64_t rows, int c, int groups, float eps, int fuse_silu, float *stats,
+                               void *stream);
 /* GroupNorm (no activation) folded into the nn.Linear that consumes it -- diffusers TransformerSpatioTemporalModel:
  * hidden = proj_in(norm(x)) -- so that the normalised tensor is never written or read:
  *   GN(x)[r][c] = (x[r][c] - mean[i][g(c)]) * rstd[i][g(c)] * gamma[c] + beta[c]      (i = instance of row r)

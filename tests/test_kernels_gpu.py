@@ -367,6 +367,68 @@ def test_groupnorm_folded_into_the_linear_layer_behind_it(inst, rows, c, n, off,
         assert float((st[:, 1] * torch.sqrt(var + 1e-5) - 1).abs().max()) <= 2e-3
 
 
+@pytest.mark.parametrize("mode,inst,rows,cin,n,off", [(0, 3, 512, 320, 320, 0.0), (1, 4, 256, 64, 640, 3.0), (2, 2, 768, 256, 256, 0.0),
+                                                      (0, 2, 1024, 128, 1280, 25.0)])
+def test_groupnorm_statistics_from_the_producing_contraction(mode, inst, rows, cin, n, off):
+    """sp_gemm_desc.gn_part + sp_groupnorm_tile_sums_f16: the contraction's epilogue leaves (sum, sum of squares) per 128-row
+    half of every 256-row tile and output column, a small kernel folds them per (instance, group), the apply pass runs --
+    against F.group_norm(+SiLU) of the contraction's stored output in fp64, for a linear layer, a 3x3 convolution (two column
+    tiles) and a temporal convolution, per-instance and all-rows statistics, and a bias that puts every group 25 standard
+    deviations off zero (un-shifted sums: the fold is fp64).  The column sums themselves are checked against the output."""
+    ops = _ops()
+    from vdpp_amd.models import weights as W
+    g = torch.Generator().manual_seed(n + rows + mode)
+    m = inst * rows
+    taps = {0: 1, 1: 9, 2: 3}[mode]
+    kw = {}
+    if mode == 1:
+        hh = 16; ww = rows // hh
+        x = h(torch.randn(inst, hh, ww, cin, generator=g))
+        wt = h(torch.randn(n, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+        wp = W.pack_conv3x3(wt.half())
+        a = x.reshape(m, cin)
+        kw.update(mode=ops.A_CONV3X3, conv=(inst, hh, ww, hh, ww, 1, 0))
+    elif mode == 2:
+        hw = rows // 3
+        a = h(torch.randn(m, cin, generator=g))
+        wt = h(torch.randn(n, cin, 3, 1, 1, generator=g) / math.sqrt(3 * cin))
+        wp = W.pack_tconv3(wt.half())
+        kw.update(mode=ops.A_TEMPORAL3, temporal=(3, hw))
+    else:
+        a = h(torch.randn(m, cin, generator=g))
+        wp = h(torch.randn(n, cin, generator=g) / math.sqrt(cin)).half()
+    bias = torch.randn(n, generator=g) + off
+    bias2 = torch.randn(n, generator=g)
+    out = torch.empty(m, n, dtype=torch.float16, device=DEV)
+    part = torch.full((m // 256, 2, n, 2), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm(a.half().to(DEV), wp.to(DEV), out, m=m, n=n, cin=cin, bias=bias.to(DEV), bias2=bias2.to(DEV), bias2_rows=m,
+             gn_part=part, **kw)
+    plain = torch.empty_like(out)
+    with ops.gemm_route(2, bm=256):             # the same 256-row ping-pong tiles the column sums run on
+        ops.gemm(a.half().to(DEV), wp.to(DEV), plain, m=m, n=n, cin=cin, bias=bias.to(DEV), bias2=bias2.to(DEV), bias2_rows=m, **kw)
+    assert torch.equal(out, plain), "asking for the column sums changed the output"
+    o64 = out.double().cpu().reshape(m // 128, 128, n)
+    want_s, want_q = o64.sum(1), (o64 * o64).sum(1)
+    got = part.double().cpu().reshape(m // 128, n, 2)
+    assert torch.isfinite(got).all()
+    assert float((got[..., 0] - want_s).abs().max()) <= 2e-3 * float(want_s.abs().max() + 128.0 * 0.02)
+    assert float((got[..., 1] - want_q).abs().max()) <= 3e-3 * float(want_q.abs().max())
+    gamma, beta = 1.0 + 0.3 * torch.randn(n, generator=g), torch.randn(n, generator=g)
+    for ni, nr in ((inst, rows), (1, m)):                       # per-instance (per-frame) and all-rows (temporal) statistics
+        y = torch.empty_like(out)
+        stats = torch.empty(ni * 32 * 2, dtype=torch.float32, device=DEV)
+        ops.groupnorm_tile_sums(out, part, gamma.to(DEV), beta.to(DEV), y, instances=ni, rows=nr, c=n, groups=32, eps=1e-6,
+                                silu=True, stats=stats)
+        ref = F.silu(F.group_norm(out.double().cpu().reshape(ni, nr, n).permute(0, 2, 1), 32, gamma.double(), beta.double(),
+                                  eps=1e-6)).permute(0, 2, 1).reshape(m, n).float()
+        check(y, ref, l2=2e-3, mx=2e-2)
+    with pytest.raises(ops.HipKernelError, match="gn_part"):
+        ops.gemm(a.half().to(DEV), wp.to(DEV), out, m=m, n=n, cin=cin, res1=plain, r1scale=1.0, gn_part=part, **kw)
+    with pytest.raises(ops.HipKernelError, match="256-row tiles"):
+        ops.groupnorm_tile_sums(out, part, gamma.to(DEV), beta.to(DEV), y, instances=m // 128, rows=128, c=n, groups=32,
+                                eps=1e-6, silu=True, stats=stats)
+
+
 def test_gemm_rejects_row_groups_that_tiles_would_straddle():
     ops = _ops()
     a = torch.zeros(640, 320, dtype=torch.float16, device=DEV)

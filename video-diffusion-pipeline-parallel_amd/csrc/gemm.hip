@@ -514,6 +514,8 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
   // ---- output-row LayerNorm statistics live in the ping-pong epilogue (one tile = whole rows)
   // per-row-group weights: a tile must lie inside one group (192-row tiles need groups of a multiple of 192 rows, ...)
   auto group_ok = [&](int bm) { return a.w_group_rows == 0 || a.w_group_rows % bm == 0; };
+  if (a.gn_part)                               // per-tile column sums live in the ping-pong epilogue of 256-row tiles
+    return launch_pp(a, 256, ok320 ? 320 : 256, s);
   if (a.ln_out) {
     const int bn = d->n <= 320 ? d->n : d->n / 2;
     int bm = makespan(d->m, d->n, 192, bn) * 1.06 < makespan(d->m, d->n, 256, bn) ? 192 : 256;
@@ -704,6 +706,14 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   a.res1 = (const f16 *)d->res1; a.res2 = (const f16 *)d->res2; a.d = (f16 *)d->d;
   a.ln_stats = d->ln_stats; a.ln_colsum = d->ln_colsum;
   a.ln_out = d->ln_out; a.ln_out_eps = d->ln_out_eps;
+  a.gn_part = nullptr;
+  if (d->gn_part) {
+    SP_REQUIRE(!d->geglu && !d->res1 && !d->res2 && !d->ln_stats && !d->ln_out && !d->euler_out && d->n_store == 0 &&
+                   d->m % 256 == 0 && (d->n % 256 == 0 || d->n % 320 == 0) && ((uintptr_t)d->gn_part & 15) == 0,
+               "sp_gemm_f16: gn_part needs whole 256-row tiles (m = %d), n a multiple of 256 or 320 (n = %d), no geglu / "
+               "residuals / folded LayerNorm / ln_out / n_store / Euler tail, and a 16-byte aligned buffer", d->m, d->n);
+    a.gn_part = d->gn_part;
+  }
   a.w_group_rows = 0; a.w_group_stride = 0;
   if (d->w_group_rows != 0) {
     // (a folded LayerNorm's column sums belong to ONE weight matrix: with one matrix per row group the mean term would be

@@ -27,6 +27,8 @@ struct GemmArgs {
   const float *ln_colsum;   // fp32 [n]: row sums of the gamma-scaled weight
   float *ln_out;            // fp32 [m][2]: (mean, rstd) of the stored output rows, or null (ping-pong kernels, n == BN)
   float ln_out_eps;
+  float *gn_part;           // fp32 [tiles_m][2][n][2]: per 128-row half of every 256-row tile, per output column, (sum, sum of
+                            // squares) of the fp32 outputs (GroupNorm statistics of the NEXT norm: sp_gemm_desc.gn_part)
   float *ln_part;           // rows spanning two tiles: fp32 [m][tiles_n][2] raw (sum, sum of squares) per tile, folded by ln_part_finalize
   f16 *d;
   const char *zero;

@@ -70,6 +70,7 @@ __device__ __forceinline__ void wait_dma(int ksteps_left) {
 // writes and the 16-byte row reads at <= 2-way bank conflicts).  The residual reads are issued before/while staging
 // so that their latency overlaps the LDS round trip, and all arithmetic precedes the first store: on gfx9 stores
 // count in vmcnt like loads, so a load consumed after a store was issued waits for that store's acknowledgement.
+#define WROWS_OF(pbm, wtm) ((pbm) / (wtm))      /* wave rows of a tile */
 template <int PBM, int BN, int TN, int TM, int WTN, int WTM, bool GEGLU, int NT>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][TM], char *smem, int tile_m,
                                             int tile_n, int wm, int wn, int tid, int fr, int fq) {
@@ -111,6 +112,40 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
 #pragma unroll
       for (int j = 0; j < TM; ++j) acc[i][j] = (acc[i][j] - st[j][0] * cs) * st[j][1] + b;
       __builtin_amdgcn_sched_barrier(0);      // one column sub-tile at a time (hoisting all row sums costs 40 registers)
+    }
+  }
+  // ---- GroupNorm statistics of the NEXT norm (gn_part; host: no residuals / geglu / LayerNorm fold, m a multiple of the
+  // tile height): per output column, (sum, sum of squares) of this wave's WTM rows, from the fp32 accumulators (bias and
+  // time-embedding row are in them; nothing is added later).  Eight in-register adds per column, then the 16 lanes that hold
+  // the same columns of different rows are folded with four DPP steps (a fixed butterfly: deterministic).  One 32-byte
+  // record per lane quad of columns; a small kernel folds tiles and columns into (mean, rstd) per (instance, group).
+  if constexpr (!GEGLU) {
+    if (p.gn_part) {
+      auto row16_sum = [](float v) {
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+        return v;
+      };
+      float *dst = p.gn_part + (((int64_t)tile_m * WROWS_OF(PBM, WTM) + wm) * p.n + (int64_t)tile_n * BN + wn * WTN) * 2;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const f32x4 v = acc[i][j] * p.oscale;
+          sm += v;
+          sq += v * v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); sq[r] = row16_sum(sq[r]); }
+        if (fr == 0) {
+          float *o = dst + (i * 16 + 4 * fq) * 2;
+          *(f32x4 *)o = (f32x4){sm[0], sq[0], sm[1], sq[1]};
+          *(f32x4 *)(o + 4) = (f32x4){sm[2], sq[2], sm[3], sq[3]};
+        }
+      }
     }
   }
   f16x8 q1[ITERS];

@@ -575,7 +575,70 @@ __global__ __launch_bounds__(256) void ln_stats_rows_kernel(const f16 *__restric
     if (li == 0 && row[p] < rows) *(float2 *)(stats + row[p] * 2) = make_float2(s[p], rsqrtf(ss[p] * (1.0f / (float)C) + eps));
 }
 
+// (mean, rstd) per (instance, group) from the per-tile column sums a contraction's epilogue left (sp_gemm_desc.gn_part:
+// [tile][half][c][2], 256-row tiles): one block per (instance, group) adds its tiles x halves x channels in a FIXED order
+// (thread t takes every 256th entry, lane 0 of wave 0 folds the 256 partials) in fp64 -- sums of un-shifted values, so the
+// cancellation of E[x^2] - mean^2 is left to the 53-bit fold (the per-tile sums are fp32 over 128 rows each).
+__global__ __launch_bounds__(256) void gn_tile_sums_finalize_kernel(const float *__restrict__ part, float *__restrict__ stats,
+                                                                   int tiles_per_inst, int c, int groups, int64_t rows,
+                                                                   float eps) {
+  __shared__ double red[256 * 2];
+  const int inst = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int cpg = c / groups;
+  const int per_tile = 2 * cpg;                                   // (half, channel) entries of this group per tile
+  const int total = tiles_per_inst * per_tile;
+  double a = 0.0, b = 0.0;
+  for (int e = tid; e < total; e += 256) {
+    const int t = e / per_tile, r = e - t * per_tile;
+    const int half = r / cpg, ch = g * cpg + (r - half * cpg);
+    const float2 v = *(const float2 *)(part + ((((int64_t)inst * tiles_per_inst + t) * 2 + half) * c + ch) * 2);
+    a += (double)v.x; b += (double)v.y;
+  }
+  red[tid * 2] = a; red[tid * 2 + 1] = b;
+  __syncthreads();
+  if (tid == 0) {
+    a = 0.0; b = 0.0;
+    for (int q = 0; q < 256; ++q) { a += red[q * 2]; b += red[q * 2 + 1]; }
+    const double cnt = (double)rows * cpg, mean = a / cnt;
+    double var = b / cnt - mean * mean; if (var < 0.0) var = 0.0;
+    stats[((int64_t)inst * groups + g) * 2] = (float)mean;
+    stats[((int64_t)inst * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 }  // namespace
+
+extern "C" int sp_groupnorm_tile_sums_f16(const void *x, int64_t ldx, const float *part, const float *gamma, const float *beta,
+                                          void *y, int instances, int64_t rows, int c, int groups, float eps, int fuse_silu,
+                                          float *stats, void *stream) {
+  SP_REQUIRE(x && y && part && stats, "sp_groupnorm_tile_sums_f16: null pointer");
+  SP_REQUIRE(ldx >= c && ldx % 8 == 0, "sp_groupnorm_tile_sums_f16: ldx=%lld must be a multiple of 8 and >= C=%d", (long long)ldx, c);
+  SP_REQUIRE(instances > 0 && rows > 0 && rows % 256 == 0 && rows / 256 <= 0x7fffffff,
+             "sp_groupnorm_tile_sums_f16: an instance must be a whole number of 256-row tiles (rows=%lld)", (long long)rows);
+  SP_REQUIRE(c % 8 == 0 && c >= 8 && c <= 4096, "sp_groupnorm_tile_sums_f16: C=%d must be a multiple of 8 in [8,4096]", c);
+  SP_REQUIRE(groups > 0 && groups <= 64 && c % groups == 0, "sp_groupnorm_tile_sums_f16: groups=%d invalid for C=%d", groups, c);
+  const int oc = c / 8;
+  const int P = gn_rows_per_iter(oc);
+  const int threads = ((oc * P + 63) / 64) * 64 < 64 ? 64 : ((oc * P + 63) / 64) * 64;
+  SP_REQUIRE(threads <= 1024, "sp_groupnorm_tile_sums_f16: C too large");
+  hipStream_t s = (hipStream_t)stream;
+  SP_CLEAR_STALE_ERROR();
+  hipLaunchKernelGGL(gn_tile_sums_finalize_kernel, dim3(instances, groups), dim3(256), 0, s, part, stats, (int)(rows / 256), c,
+                     groups, rows, eps);
+  SP_CHECK_LAUNCH("sp_groupnorm_tile_sums_f16(finalize)");
+  int64_t blocks_y = (2048 + instances - 1) / instances;
+  int64_t maxb = (rows + 16 * P - 1) / (16 * P);
+  if (blocks_y > maxb) blocks_y = maxb;
+  if (blocks_y < 1) blocks_y = 1;
+  int64_t rpb = (rows + blocks_y - 1) / blocks_y;
+  rpb = (rpb + 4 * P - 1) / (4 * P) * (4 * P);                 // whole batches of four loads per thread
+  blocks_y = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(instances, (unsigned)blocks_y), dim3(threads), 0, s, (const f16 *)x,
+                     (const float *)stats, (const float *)nullptr, 0, eps, gamma, beta, (f16 *)y, rows, c, groups, fuse_silu, rpb,
+                     ldx);
+  SP_CHECK_LAUNCH("sp_groupnorm_tile_sums_f16(apply)");
+  return SP_OK;
+}
 
 extern "C" size_t sp_groupnorm_ws_bytes(int instances, int64_t rows, int c, int groups) {
   if (instances <= 0 || rows <= 0 || c <= 0 || groups <= 0) return 0;

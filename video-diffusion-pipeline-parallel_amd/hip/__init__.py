@@ -38,6 +38,7 @@ class GemmDesc(ctypes.Structure):
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
         ("ln_out", ctypes.c_void_p), ("ln_out_eps", ctypes.c_float),
         ("w_group_rows", ctypes.c_int64), ("w_group_stride", ctypes.c_int64),
+        ("gn_part", ctypes.c_void_p),
     ]
 
 
@@ -57,6 +58,7 @@ SIGNATURES = {
     "sp_groupnorm_ws_bytes": (_Z, [_I, _L, _I, _I]),
     "sp_groupnorm_f16": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _Z, _P]),
     "sp_groupnorm_ld_f16": (_I, [_P, _L, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _Z, _P]),
+    "sp_groupnorm_tile_sums_f16": (_I, [_P, _L, _P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _P]),
     "sp_groupnorm_fold_linear_f16": (_I, [_P, _L, _P, _P, _I, _L, _I, _I, _F, _P, _P, _I, _P, _P, _P, _Z, _P]),
     "sp_layernorm_f16": (_I, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _F, _P]),
     "sp_ln_stats_f16": (_I, [_P, _P, _L, _P, _P, _L, _I, _F, _P]),

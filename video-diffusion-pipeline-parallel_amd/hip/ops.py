@@ -82,7 +82,7 @@ def _rows(t: torch.Tensor, name: str, ld: int) -> torch.Tensor:
 def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=None, bias=None,
          bias2=None, bias2_rows=0, ldb2=0, res1=None, r1scale=1.0, res2=None, r2scale=1.0, oscale=1.0,
          geglu=False, n_store=0, ldd=None, ldr1=None, ldr2=None, ln_stats=None, ln_colsum=None, euler=None,
-         workspace=None, ln_out=None, ln_out_eps=1e-5, w_group_rows=0, w_group_stride=0):
+         workspace=None, ln_out=None, ln_out_eps=1e-5, w_group_rows=0, w_group_stride=0, gn_part=None):
     """``out[m][:] = epilogue(sum_taps A_tap @ W^T)``; see ``sp_gemm_desc`` in include/svdpipe.h.
     ``ln_stats`` / ``ln_colsum``: LayerNorm folded into the contraction (``a`` is the UN-normalised tensor).
     ``w_group_rows`` / ``w_group_stride``: ``w`` holds one weight matrix per group of that many output rows (a GroupNorm
@@ -118,6 +118,10 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
             raise ValueError("ln_out must be a contiguous float32 [m][2] tensor")
         d.ln_out, d.ln_out_eps = ln_out.data_ptr(), float(ln_out_eps)
     d.w_group_rows, d.w_group_stride = int(w_group_rows), int(w_group_stride)
+    if gn_part is not None:            # fp32 [m/256][2][n][2]: per-tile column sums for the next GroupNorm (svdpipe.h)
+        if gn_part.dtype != torch.float32 or not gn_part.is_cuda or gn_part.numel() < (m // 256) * 2 * n * 2:
+            raise TypeError("gn_part must be a float32 HIP tensor of (m/256)*2*n*2 elements")
+        d.gn_part = gn_part.data_ptr()
     taps = 9 if mode == A_CONV3X3 else 3 if mode == A_TEMPORAL3 else 1
     # algorithmic bytes of this launch: every operand element once (A without tap re-reads), output and residuals once
     a_rows = d.n_img * d.hin * d.win if mode == A_CONV3X3 else m
@@ -186,6 +190,17 @@ def groupnorm(x, gamma, beta, y, *, instances, rows, c, groups, eps, silu, ws, l
         _check(load().sp_groupnorm_ld_f16(_rows(x, "x", ldx).data_ptr(), ldx, _ptr(gamma), _ptr(beta),
                                           _f16(y, "y").data_ptr(), instances, rows, c, groups, eps, int(silu),
                                           ws.data_ptr(), ws.numel() * ws.element_size(), _stream()), "sp_groupnorm_f16")
+    return y
+
+
+def groupnorm_tile_sums(x, part, gamma, beta, y, *, instances, rows, c, groups, eps, silu, stats, ldx=None):
+    """GroupNorm(+SiLU) of ``x`` from the per-tile column sums its producing contraction left in ``part``
+    (``gemm(..., gn_part=part)``): no statistics pass over ``x`` (``sp_groupnorm_tile_sums_f16``)."""
+    ldx = int(ldx if ldx is not None else x.stride(0))
+    with _Timed("groupnorm", 0.0, 2 * 2.0 * instances * rows * c):
+        _check(load().sp_groupnorm_tile_sums_f16(_f16(x, "x").data_ptr(), ldx, part.data_ptr(), _ptr(gamma), _ptr(beta),
+                                                 _f16(y, "y").data_ptr(), instances, rows, c, groups, float(eps), int(silu),
+                                                 stats.data_ptr(), _stream()), "sp_groupnorm_tile_sums_f16")
     return y
 
 

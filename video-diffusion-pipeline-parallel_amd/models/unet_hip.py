@@ -154,6 +154,9 @@ class SVDUNetHIP:
         self.long_attention = (os.environ.get("VDPP_LONG_ATTN", "1") != "0") if long_attention is None else bool(long_attention)
         # the 16 transformer-entry GroupNorms folded into proj_in where a frame is whole tiles (VDPP_FOLD_GN=0: never)
         self.fold_groupnorm = os.environ.get("VDPP_FOLD_GN", "1") != "0"
+        # statistics of a resnet's second norms (norm2 / temporal norm2: inputs without a residual) out of the producing
+        # convolution's epilogue where a frame is whole 256-row tiles (VDPP_GN_EPILOGUE=0: always the statistics pass)
+        self.gn_from_epilogue = os.environ.get("VDPP_GN_EPILOGUE", "1") != "0"
         self.device = dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("SVDUNetHIP runs on an MI355X HIP device only (no CPU fallback)")
@@ -369,6 +372,14 @@ class SVDUNetHIP:
                       w_group_stride=w_groups[0].shape[1] * w_groups[0].shape[2])
         st = None
         ws = r.sk_ws if m <= self.SPLITK_MAX_ROWS else None
+        # ``gn_next``: this output goes straight into a GroupNorm (no residual in between): where the tiles allow it the
+        # epilogue leaves per-tile column sums beside the output and _gn folds them instead of reading the tensor again
+        gn_part = None
+        if kw.pop("gn_next", False) and self.gn_from_epilogue and m % 256 == 0 and layer.n == layer.n_true \
+                and not layer.geglu and (layer.n % 320 == 0 or layer.n % 256 == 0) and r.hw % 256 == 0 \
+                and kw.get("res1") is None and kw.get("res2") is None and layer.colsum is None and out is None:
+            gn_part = torch.empty((m // 256, 2, layer.n, 2), dtype=torch.float32, device=self.device)
+            kw.update(gn_part=gn_part)
         st_buf = kw.pop("ln_out_buf", None)             # caller-provided rows of a larger statistics tensor (_ff_pair chunks)
         if ln_next is not None and self._ln_out_ok(layer) and "euler" not in kw:
             st = st_buf if st_buf is not None else torch.empty((m, 2), dtype=torch.float32, device=self.device)
@@ -390,6 +401,8 @@ class SVDUNetHIP:
         ops.gemm(a, weight, out, m=m, n=layer.n, cin=layer.cin, mode=layer.mode, conv=conv, temporal=temporal,
                  bias=bias, geglu=layer.geglu, n_store=n_store, ldd=out.stride(0), lda=a.stride(0),
                  ln_colsum=layer.colsum, workspace=ws, **kw)
+        if gn_part is not None:
+            out._gn_tile_sums = (gn_part, out.data_ptr(), _version(out), tuple(out.shape))
         if st is not None and st_buf is None:
             # valid for exactly this tensor object in exactly this state (checked in _ln_stats): a view, a slice or an
             # in-place write after the contraction silently falls back to the statistics pass
@@ -415,6 +428,13 @@ class SVDUNetHIP:
         c = x.shape[1]
         inst, rows = (r.b, r.f * r.hw) if temporal else (r.b * r.f, r.hw)
         y = self._buf(x.shape[0], c)
+        have = getattr(x, "_gn_tile_sums", None)
+        if (have is not None and have[1] == x.data_ptr() and have[2] == _version(x) and have[3] == tuple(x.shape)
+                and rows % 256 == 0 and x.stride(0) == c):
+            stats = torch.empty((inst, self.cfg.norm_groups, 2), dtype=torch.float32, device=self.device)
+            ops.groupnorm_tile_sums(x, have[0], norm.g, norm.b, y, instances=inst, rows=rows, c=c,
+                                    groups=self.cfg.norm_groups, eps=norm.eps, silu=silu, stats=stats)
+            return y
         ops.groupnorm(x, norm.g, norm.b, y, instances=inst, rows=rows, c=c, groups=self.cfg.norm_groups,
                       eps=norm.eps, silu=silu, ws=r.gn_ws, ldx=x.stride(0))
         return y
@@ -435,13 +455,13 @@ class SVDUNetHIP:
         geom, _, _ = self._conv_geom(r)
         t = self._gn(r, p["n1"], x, temporal=False, silu=True)
         n1 = p["c1"].n
-        t = self._gemm(r, p["c1"], t, conv=geom, bias2=r.temb[p["te_s"]:p["te_s"] + n1], bias2_rows=r.m)
+        t = self._gemm(r, p["c1"], t, conv=geom, bias2=r.temb[p["te_s"]:p["te_s"] + n1], bias2_rows=r.m, gn_next=True)
         t = self._gn(r, p["n2"], t, temporal=False, silu=True)
         skip = x if p["sc"] is None else self._gemm(r, p["sc"], x)
         s = self._gemm(r, p["c2"], t, conv=geom, res1=skip, r1scale=1.0)
         # temporal branch + AlphaBlender: alpha*s + (1-alpha)*(s + conv2(...)) = s + (1-alpha)*conv2(...)
         t = self._gn(r, p["tn1"], s, temporal=True, silu=True)
-        t = self._gemm(r, p["tc1"], t, bias2=r.temb[p["te_t"]:p["te_t"] + p["cout"]], bias2_rows=r.m)
+        t = self._gemm(r, p["tc1"], t, bias2=r.temb[p["te_t"]:p["te_t"] + p["cout"]], bias2_rows=r.m, gn_next=True)
         t = self._gn(r, p["tn2"], t, temporal=True, silu=True)
         return self._gemm(r, p["tc2"], t, oscale=1.0 - p["alpha"], res1=s, r1scale=1.0, out=out)
 
