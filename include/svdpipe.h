@@ -115,9 +115,10 @@ typedef struct sp_gemm_desc {
   /* GroupNorm statistics of the NEXT norm out of this contraction's epilogue (round 5): gn_part = fp32
      [m/256][2][n][2] -- for every 256-row tile, each of its two 128-row halves and every output column, (sum, sum of
      squares) of the fp32 output values of the half's rows (bias / bias2 included, before the rounding to fp16).
+     With residuals the sums are of the FINAL stored fp16 values instead (the tile is rebuilt in LDS behind the stores).
      sp_groupnorm_tile_sums_f16 folds them into the (mean, rstd) of any instance that is a whole number of tiles and
      normalises d without a statistics pass over it.  Needs m a multiple of 256, n a multiple of 256 or 320, no geglu /
-     residuals / folded LayerNorm / ln_out / n_store / Euler tail; the call runs on the 256-row ping-pong tiles.  Sums
+     folded LayerNorm / ln_out / n_store / Euler tail; the call runs on the 256-row ping-pong tiles.  Sums
      are folded in a fixed order (bit-reproducible).  NULL = off. */
   float *gn_part;
 } sp_gemm_desc;
@@ -184,6 +185,10 @@ int sp_groupnorm_ld_f16(const void *x, int64_t ldx, const float *gamma, const fl
 int sp_groupnorm_tile_sums_f16(const void *x, int64_t ldx, const float *part, const float *gamma, const float *beta, void *y,
                                int instances, int64_t rows, int c, int groups, float eps, int fuse_silu, float *stats,
                                void *stream);
+/* sp_groupnorm_fold_linear_f16 (below) with the statistics folded from such column sums instead of a pass over x. */
+int sp_groupnorm_fold_linear_tile_sums_f16(const float *part, const float *gamma, const float *beta, int instances, int64_t rows,
+                                           int c, int groups, float eps, const void *w, const float *bias, int n, void *w_out,
+                                           float *bias_out, float *stats, void *stream);
 /* GroupNorm (no activation) folded into the nn.Linear that consumes it -- diffusers TransformerSpatioTemporalModel:
  * hidden = proj_in(norm(x)) -- so that the normalised tensor is never written or read:
  *   GN(x)[r][c] = (x[r][c] - mean[i][g(c)]) * rstd[i][g(c)] * gamma[c] + beta[c]      (i = instance of row r)

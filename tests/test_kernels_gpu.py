@@ -37,6 +37,10 @@ def check(out, ref, l2=2e-3, mx=1e-2):
     assert e <= l2 and m <= mx, f"rel_l2={e:.3e} max_rel={m:.3e}"
 
 
+def rel_l2_t(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
 def h(t):  # fp16-rounded fp32 copy (what the kernel actually sees)
     return t.half().float()
 
@@ -422,8 +426,41 @@ def test_groupnorm_statistics_from_the_producing_contraction(mode, inst, rows, c
         ref = F.silu(F.group_norm(out.double().cpu().reshape(ni, nr, n).permute(0, 2, 1), 32, gamma.double(), beta.double(),
                                   eps=1e-6)).permute(0, 2, 1).reshape(m, n).float()
         check(y, ref, l2=2e-3, mx=2e-2)
+    # ---- with residuals the sums are of the FINAL stored values (the tile is rebuilt in LDS behind the stores)
+    r1 = torch.randn(m, n, generator=g).half().to(DEV)
+    r2 = (torch.randn(m, n, generator=g) * 2.0 + off).half().to(DEV)
+    rkw = dict(res1=r1, r1scale=0.75, res2=r2, r2scale=1.0, oscale=0.5)
+    out_r = torch.empty(m, n, dtype=torch.float16, device=DEV)
+    part_r = torch.full((m // 256, 2, n, 2), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm(a.half().to(DEV), wp.to(DEV), out_r, m=m, n=n, cin=cin, bias=bias.to(DEV), gn_part=part_r, **rkw, **kw)
+    with ops.gemm_route(2, bm=256):
+        ops.gemm(a.half().to(DEV), wp.to(DEV), plain, m=m, n=n, cin=cin, bias=bias.to(DEV), **rkw, **kw)
+    assert torch.equal(out_r, plain), "asking for the column sums changed the output (residual case)"
+    o64 = out_r.double().cpu().reshape(m // 128, 128, n)
+    got = part_r.double().cpu().reshape(m // 128, n, 2)
+    assert torch.isfinite(got).all()
+    assert float((got[..., 0] - o64.sum(1)).abs().max()) <= 1e-5 * float(o64.abs().sum(1).max())      # sums of the rounded values
+    assert float((got[..., 1] - (o64 * o64).sum(1)).abs().max()) <= 1e-5 * float((o64 * o64).sum(1).max())
+    y = torch.empty_like(out_r)
+    stats = torch.empty(inst * 32 * 2, dtype=torch.float32, device=DEV)
+    ops.groupnorm_tile_sums(out_r, part_r, gamma.to(DEV), beta.to(DEV), y, instances=inst, rows=rows, c=n, groups=32, eps=1e-6,
+                            silu=False, stats=stats)
+    ref = F.group_norm(out_r.double().cpu().reshape(inst, rows, n).permute(0, 2, 1), 32, gamma.double(), beta.double(),
+                       eps=1e-6).permute(0, 2, 1).reshape(m, n).float()
+    check(y, ref, l2=2e-3, mx=2e-2)
+    if n in (256, 320, 640):     # and the fold into the linear layer behind the norm from the same sums
+        wl = h(torch.randn(n, n, generator=g) / math.sqrt(n)).half().to(DEV)
+        bl = torch.randn(n, generator=g).to(DEV)
+        w_a = torch.empty(inst, n, n, dtype=torch.float16, device=DEV); b_a = torch.empty(inst, n, dtype=torch.float32, device=DEV)
+        w_b = torch.empty_like(w_a); b_b = torch.empty_like(b_a)
+        ws = torch.empty(ops.groupnorm_ws_bytes(inst, rows, n, 32), dtype=torch.uint8, device=DEV)
+        ops.groupnorm_fold_linear(out_r, gamma.to(DEV), beta.to(DEV), wl, bl, w_a, b_a, instances=inst, rows=rows, c=n,
+                                  groups=32, eps=1e-6, n=n, ws=ws, ldx=n)
+        ops.groupnorm_fold_linear_tile_sums(part_r, gamma.to(DEV), beta.to(DEV), wl, bl, w_b, b_b, instances=inst, rows=rows,
+                                            c=n, groups=32, eps=1e-6, n=n, stats=stats)
+        assert rel_l2_t(w_b.float(), w_a.float()) <= 1e-3 and float((b_b - b_a).abs().max()) <= 2e-2 * float(b_a.abs().max())
     with pytest.raises(ops.HipKernelError, match="gn_part"):
-        ops.gemm(a.half().to(DEV), wp.to(DEV), out, m=m, n=n, cin=cin, res1=plain, r1scale=1.0, gn_part=part, **kw)
+        ops.gemm(a.half().to(DEV), wp.to(DEV), out[:, :n // 2], m=m, n=n, cin=cin, geglu=True, gn_part=part, ldd=n, **kw)
     with pytest.raises(ops.HipKernelError, match="256-row tiles"):
         ops.groupnorm_tile_sums(out, part, gamma.to(DEV), beta.to(DEV), y, instances=m // 128, rows=128, c=n, groups=32,
                                 eps=1e-6, silu=True, stats=stats)

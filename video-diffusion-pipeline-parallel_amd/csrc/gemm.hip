@@ -708,10 +708,10 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   a.ln_out = d->ln_out; a.ln_out_eps = d->ln_out_eps;
   a.gn_part = nullptr;
   if (d->gn_part) {
-    SP_REQUIRE(!d->geglu && !d->res1 && !d->res2 && !d->ln_stats && !d->ln_out && !d->euler_out && d->n_store == 0 &&
+    SP_REQUIRE(!d->geglu && !d->ln_stats && !d->ln_out && !d->euler_out && d->n_store == 0 &&
                    d->m % 256 == 0 && (d->n % 256 == 0 || d->n % 320 == 0) && ((uintptr_t)d->gn_part & 15) == 0,
                "sp_gemm_f16: gn_part needs whole 256-row tiles (m = %d), n a multiple of 256 or 320 (n = %d), no geglu / "
-               "residuals / folded LayerNorm / ln_out / n_store / Euler tail, and a 16-byte aligned buffer", d->m, d->n);
+               "folded LayerNorm / ln_out / n_store / Euler tail, and a 16-byte aligned buffer", d->m, d->n);
     a.gn_part = d->gn_part;
   }
   a.w_group_rows = 0; a.w_group_stride = 0;

@@ -71,7 +71,7 @@ __device__ __forceinline__ void wait_dma(int ksteps_left) {
 // so that their latency overlaps the LDS round trip, and all arithmetic precedes the first store: on gfx9 stores
 // count in vmcnt like loads, so a load consumed after a store was issued waits for that store's acknowledgement.
 #define WROWS_OF(pbm, wtm) ((pbm) / (wtm))      /* wave rows of a tile */
-template <int PBM, int BN, int TN, int TM, int WTN, int WTM, bool GEGLU, int NT>
+template <int PBM, int BN, int TN, int TM, int WTN, int WTM, bool GEGLU, int NT, bool GNRES = false>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][TM], char *smem, int tile_m,
                                             int tile_n, int wm, int wn, int tid, int fr, int fq) {
   constexpr int bno = GEGLU ? BN / 2 : BN;
@@ -120,7 +120,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
   // the same columns of different rows are folded with four DPP steps (a fixed butterfly: deterministic).  One 32-byte
   // record per lane quad of columns; a small kernel folds tiles and columns into (mean, rstd) per (instance, group).
   if constexpr (!GEGLU) {
-    if (p.gn_part) {
+    if (p.gn_part && !p.res1 && !p.res2) {
       auto row16_sum = [](float v) {
         v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
         v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
@@ -189,6 +189,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
     const int r = idx / cpr, c = idx - r * cpr;      // (idx >= NCH reads idle ring memory, never stored)
     o[it] = *(const f16x8 *)(smem + r * (bno * 2) + ((c ^ (r & 7)) << 4));
   }
+  // (GroupNorm column sums with residuals, below: the final values go back into this LDS image while they are stored)
+  // (its own kernel instantiation, EXP = 2048: the default one keeps its register allocation)
+  const bool gn_res = GNRES && !GEGLU && PBM == 256 && p.gn_part && (p.res1 || p.res2);
+  if (gn_res) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave has read its part of the tile
   if (p.res1 || p.res2) {
     constexpr int G = (ITERS + 3) / 4;   // res2 (one GEMM family) is fetched here, in groups to bound registers
 #pragma unroll
@@ -264,12 +268,55 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
       else
 #endif
       *(f16x8 *)(p.d + m * p.ldd + col) = o[it];
+      if (gn_res) *(f16x8 *)(smem + r * (bno * 2) + ((c ^ (r & 7)) << 4)) = o[it];
     } else {   // ragged last chunk (n_store): the residuals were not prefetched for it
       for (int e = 0; e < nstore - col; ++e) {
         float f = (float)o[it][e];
         if (p.res1) f += p.r1scale * (float)p.res1[m * p.ldr1 + col + e];
         if (p.res2) f += p.r2scale * (float)p.res2[m * p.ldr2 + col + e];
         p.d[m * p.ldd + col + e] = (f16)f;
+      }
+    }
+  }
+  // ---- GroupNorm statistics of the NEXT norm when residuals were added (gn_part; host: m a multiple of PBM = 256, no
+  // n_store): the sums have to come from the FINAL values, which exist in the copy-out layout only (8 channels of one
+  // row per thread, the column changing from pass to pass).  So the final fp16 tile goes back into the idle LDS image
+  // while it is stored (LDS traffic does not queue behind the stores), then every thread of the first 2*RG*Q sums one quad of
+  // columns over its share of a 128-row half, the RG partials of a (half, quad) meet in LDS and are added in a fixed order.
+  // Same record format as the accumulator path above ([tile][half][column][2]); sums of the rounded values.
+  if constexpr (GNRES && !GEGLU && PBM == 256) {
+    if (gn_res) {
+      constexpr int Q = bno / 4, RG = NT / (2 * Q), RPG = (128 + RG - 1) / RG;     // quads per row, row groups per half, rows each
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // the final tile is in LDS
+      const int quad = tid % Q, grp = tid / Q;
+      float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+      if (grp < 2 * RG) {
+        const int half = grp / RG, sub = grp - half * RG;
+        const int r0 = half * 128 + sub * RPG, r1 = min(r0 + RPG, half * 128 + 128);
+        const int col = quad * 4;
+        for (int r = r0; r < r1; ++r) {
+          const f16x4 v = *(const f16x4 *)(smem + r * (bno * 2) + ((((col >> 3) ^ (r & 7))) << 4) + (col & 4) * 2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float f = (float)v[e]; sm[e] += f; sq[e] = fmaf(f, f, sq[e]); }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // the tile has been read: its memory takes the partials
+      float *pt = (float *)smem;
+      if (grp < 2 * RG) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pt[(grp * Q + quad) * 8 + 2 * e] = sm[e]; pt[(grp * Q + quad) * 8 + 2 * e + 1] = sq[e]; }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid < 2 * Q) {
+        const int half = tid / Q, qd = tid - half * Q;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        for (int sub = 0; sub < RG; ++sub) {
+          const float *src = pt + ((half * RG + sub) * Q + qd) * 8;
+          a += *(const f32x4 *)src; b += *(const f32x4 *)(src + 4);
+        }
+        float *dst = p.gn_part + (((int64_t)tile_m * 2 + half) * p.n + (int64_t)tile_n * bno + qd * 4) * 2;
+        *(f32x4 *)dst = a;
+        *(f32x4 *)(dst + 4) = b;
       }
     }
   }
@@ -689,7 +736,7 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
   } else if (p.geglu) {
     if constexpr (TN % 2 == 0) pp_epilogue<PBM, BN, TN, TM, WTN, WTM, true, NT>(p, acc, smem, tile_m, tile_n, wm, wn, tid, fr, fq);
   } else {
-    pp_epilogue<PBM, BN, TN, TM, WTN, WTM, false, NT>(p, acc, smem, tile_m, tile_n, wm, wn, tid, fr, fq);
+    pp_epilogue<PBM, BN, TN, TM, WTN, WTM, false, NT, (EXP & 2048) != 0>(p, acc, smem, tile_m, tile_n, wm, wn, tid, fr, fq);
   }
   PP_TRACE(3);
 }
@@ -717,6 +764,9 @@ int launch_pp(GemmArgs &a, hipStream_t s) {
 
 int launch_pp(GemmArgs &a, int bm, int bn, hipStream_t s) {
   if (a.ksplit >= 1 && a.partial) return launch_pp<256, 256, 128>(a, s);   // raw fp32 sums per K slice (1 slice: sp_gemm_f32out_f16)
+  // GroupNorm column sums of an output that residuals are added to: the copy-out of this instantiation also rebuilds the
+  // final tile in LDS and sums its columns there (the no-residual case sums the accumulators in the default kernels)
+  if (a.gn_part && (a.res1 || a.res2)) return bn == 256 ? launch_pp<256, 256, 2048>(a, s) : launch_pp<256, 320, 2048>(a, s);
 #ifdef SP_GEMM_EXPERIMENTS
   if (bm == 256 && bn == 256) switch (a.dbg) {
     case 1: return launch_pp<256, 256, 1>(a, s);

@@ -640,6 +640,28 @@ extern "C" int sp_groupnorm_tile_sums_f16(const void *x, int64_t ldx, const floa
   return SP_OK;
 }
 
+// sp_groupnorm_fold_linear_f16 with the statistics taken from a producer's per-tile column sums instead of a pass over x
+extern "C" int sp_groupnorm_fold_linear_tile_sums_f16(const float *part, const float *gamma, const float *beta, int instances,
+                                                      int64_t rows, int c, int groups, float eps, const void *w,
+                                                      const float *bias, int n, void *w_out, float *bias_out, float *stats,
+                                                      void *stream) {
+  SP_REQUIRE(part && w && w_out && bias_out && stats, "sp_groupnorm_fold_linear_tile_sums_f16: null pointer");
+  SP_REQUIRE(instances > 0 && n > 0 && rows > 0 && rows % 256 == 0 && rows / 256 <= 0x7fffffff,
+             "sp_groupnorm_fold_linear_tile_sums_f16: an instance must be a whole number of 256-row tiles (rows=%lld)", (long long)rows);
+  SP_REQUIRE(c % 8 == 0 && c >= 8 && c <= 4096, "sp_groupnorm_fold_linear_tile_sums_f16: C=%d must be a multiple of 8 in [8,4096]", c);
+  SP_REQUIRE(groups > 0 && groups <= 64 && c % groups == 0, "sp_groupnorm_fold_linear_tile_sums_f16: groups=%d invalid for C=%d", groups, c);
+  hipStream_t s = (hipStream_t)stream;
+  SP_CLEAR_STALE_ERROR();
+  hipLaunchKernelGGL(gn_tile_sums_finalize_kernel, dim3(instances, groups), dim3(256), 0, s, part, stats, (int)(rows / 256), c,
+                     groups, rows, eps);
+  SP_CHECK_LAUNCH("sp_groupnorm_fold_linear_tile_sums_f16(finalize)");
+  hipLaunchKernelGGL(gn_fold_linear_kernel, dim3(instances, (n + GN_FOLD_ROWS - 1) / GN_FOLD_ROWS), dim3(256),
+                     (size_t)3 * c * sizeof(float), s, (const float *)stats, (const f16 *)w, gamma, beta, bias, (f16 *)w_out,
+                     bias_out, n, c, groups);
+  SP_CHECK_LAUNCH("sp_groupnorm_fold_linear_tile_sums_f16(fold)");
+  return SP_OK;
+}
+
 extern "C" size_t sp_groupnorm_ws_bytes(int instances, int64_t rows, int c, int groups) {
   if (instances <= 0 || rows <= 0 || c <= 0 || groups <= 0) return 0;
   return (size_t)instances * (512 + 1) * groups * 2 * sizeof(float);

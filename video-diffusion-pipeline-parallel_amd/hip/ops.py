@@ -204,6 +204,15 @@ def groupnorm_tile_sums(x, part, gamma, beta, y, *, instances, rows, c, groups, 
     return y
 
 
+def groupnorm_fold_linear_tile_sums(part, gamma, beta, w, bias, w_out, bias_out, *, instances, rows, c, groups, eps, n, stats):
+    """``groupnorm_fold_linear`` with the statistics folded from a producer's per-tile column sums (``gemm(..., gn_part=)``)."""
+    _check(load().sp_groupnorm_fold_linear_tile_sums_f16(part.data_ptr(), _ptr(gamma), _ptr(beta), instances, rows, c, groups,
+                                                         float(eps), _f16(w, "w").data_ptr(), _ptr(bias), n,
+                                                         _f16(w_out, "w_out").data_ptr(), bias_out.data_ptr(),
+                                                         stats.data_ptr(), _stream()),
+           "sp_groupnorm_fold_linear_tile_sums_f16")
+
+
 def groupnorm_fold_linear(x, gamma, beta, w, bias, w_out, bias_out, *, instances, rows, c, groups, eps, n, ws, ldx=None):
     """GroupNorm (no activation) folded into the linear layer ``w`` [n][c] behind it: ONE pass over ``x`` (statistics) and
     ``w_out`` [instances][n][c] fp16 / ``bias_out`` [instances][n] fp32 for ``gemm(x, w_out, ..., w_group_rows=rows,

@@ -157,6 +157,9 @@ class SVDUNetHIP:
         # statistics of a resnet's second norms (norm2 / temporal norm2: inputs without a residual) out of the producing
         # convolution's epilogue where a frame is whole 256-row tiles (VDPP_GN_EPILOGUE=0: always the statistics pass)
         self.gn_from_epilogue = os.environ.get("VDPP_GN_EPILOGUE", "1") != "0"
+        # ... also for outputs that residuals are added to (the final tile is rebuilt in LDS and summed there); 0: only
+        # the no-residual producers (sums straight from the accumulators)
+        self.gn_epilogue_residual = os.environ.get("VDPP_GN_EPILOGUE_RES", "1") != "0"
         self.device = dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("SVDUNetHIP runs on an MI355X HIP device only (no CPU fallback)")
@@ -377,7 +380,8 @@ class SVDUNetHIP:
         gn_part = None
         if kw.pop("gn_next", False) and self.gn_from_epilogue and m % 256 == 0 and layer.n == layer.n_true \
                 and not layer.geglu and (layer.n % 320 == 0 or layer.n % 256 == 0) and r.hw % 256 == 0 \
-                and kw.get("res1") is None and kw.get("res2") is None and layer.colsum is None and out is None:
+                and layer.colsum is None and ln_next is None and "euler" not in kw and w_groups is None \
+                and (self.gn_epilogue_residual or (kw.get("res1") is None and kw.get("res2") is None)):
             gn_part = torch.empty((m // 256, 2, layer.n, 2), dtype=torch.float32, device=self.device)
             kw.update(gn_part=gn_part)
         st_buf = kw.pop("ln_out_buf", None)             # caller-provided rows of a larger statistics tensor (_ff_pair chunks)
@@ -424,16 +428,25 @@ class SVDUNetHIP:
         ops.ln_stats(x, st, rows=x.shape[0], c=x.shape[1], eps=layer.ln_eps, **kw)
         return st
 
+    @staticmethod
+    def _tile_sums(x, rows):
+        """The per-tile column sums the contraction that produced x left beside it (``_gemm(gn_next=True)``), if they are
+        for exactly this tensor in this state and an instance of ``rows`` rows is whole 256-row tiles; else None."""
+        have = getattr(x, "_gn_tile_sums", None)
+        if (have is not None and have[1] == x.data_ptr() and have[2] == _version(x) and have[3] == tuple(x.shape)
+                and rows % 256 == 0):
+            return have[0]
+        return None
+
     def _gn(self, r: _Run, norm: _Norm, x, *, temporal: bool, silu: bool):
         c = x.shape[1]
         inst, rows = (r.b, r.f * r.hw) if temporal else (r.b * r.f, r.hw)
         y = self._buf(x.shape[0], c)
-        have = getattr(x, "_gn_tile_sums", None)
-        if (have is not None and have[1] == x.data_ptr() and have[2] == _version(x) and have[3] == tuple(x.shape)
-                and rows % 256 == 0 and x.stride(0) == c):
+        part = self._tile_sums(x, rows)
+        if part is not None:
             stats = torch.empty((inst, self.cfg.norm_groups, 2), dtype=torch.float32, device=self.device)
-            ops.groupnorm_tile_sums(x, have[0], norm.g, norm.b, y, instances=inst, rows=rows, c=c,
-                                    groups=self.cfg.norm_groups, eps=norm.eps, silu=silu, stats=stats)
+            ops.groupnorm_tile_sums(x, part, norm.g, norm.b, y, instances=inst, rows=rows, c=c,
+                                    groups=self.cfg.norm_groups, eps=norm.eps, silu=silu, stats=stats, ldx=x.stride(0))
             return y
         ops.groupnorm(x, norm.g, norm.b, y, instances=inst, rows=rows, c=c, groups=self.cfg.norm_groups,
                       eps=norm.eps, silu=silu, ws=r.gn_ws, ldx=x.stride(0))
@@ -450,20 +463,22 @@ class SVDUNetHIP:
         return (r.b * r.f, r.h, r.w, ho, wo, stride, ups), ho, wo
 
     # ------------------------------------------------------------------ blocks
-    def _run_resblock(self, r: _Run, p, x, out=None):
-        """``out``: where the block's result goes (a half of a concatenation buffer), default a fresh tensor."""
+    def _run_resblock(self, r: _Run, p, x, out=None, gn_next=False):
+        """``out``: where the block's result goes (a half of a concatenation buffer), default a fresh tensor.
+        ``gn_next``: the result goes straight into a GroupNorm (a transformer's entry norm, ``conv_norm_out``): ask the last
+        contraction for the column sums."""
         geom, _, _ = self._conv_geom(r)
         t = self._gn(r, p["n1"], x, temporal=False, silu=True)
         n1 = p["c1"].n
         t = self._gemm(r, p["c1"], t, conv=geom, bias2=r.temb[p["te_s"]:p["te_s"] + n1], bias2_rows=r.m, gn_next=True)
         t = self._gn(r, p["n2"], t, temporal=False, silu=True)
         skip = x if p["sc"] is None else self._gemm(r, p["sc"], x)
-        s = self._gemm(r, p["c2"], t, conv=geom, res1=skip, r1scale=1.0)
+        s = self._gemm(r, p["c2"], t, conv=geom, res1=skip, r1scale=1.0, gn_next=True)
         # temporal branch + AlphaBlender: alpha*s + (1-alpha)*(s + conv2(...)) = s + (1-alpha)*conv2(...)
         t = self._gn(r, p["tn1"], s, temporal=True, silu=True)
         t = self._gemm(r, p["tc1"], t, bias2=r.temb[p["te_t"]:p["te_t"] + p["cout"]], bias2_rows=r.m, gn_next=True)
         t = self._gn(r, p["tn2"], t, temporal=True, silu=True)
-        return self._gemm(r, p["tc2"], t, oscale=1.0 - p["alpha"], res1=s, r1scale=1.0, out=out)
+        return self._gemm(r, p["tc2"], t, oscale=1.0 - p["alpha"], res1=s, r1scale=1.0, out=out, gn_next=gn_next)
 
     def _cross_vec(self, r: _Run, x):
         """to_out(to_v(ctx)) + b_out for the single context token -> fp32 [B][C] (computed by _small_gemvs)."""
@@ -516,9 +531,16 @@ class SVDUNetHIP:
                 and inst * c * c * 2 <= self.GN_FOLD_MAX_WEIGHT_BYTES):
             w_f = torch.empty((inst, c, c), dtype=torch.float16, device=self.device)
             b_f = torch.empty((inst, c), dtype=torch.float32, device=self.device)
-            ops.groupnorm_fold_linear(x, p["norm"].g, p["norm"].b, p["pin"].w, p["pin"].bias, w_f, b_f, instances=inst,
-                                      rows=r.hw, c=c, groups=self.cfg.norm_groups, eps=p["norm"].eps, n=c, ws=r.gn_ws,
-                                      ldx=x.stride(0))
+            part = self._tile_sums(x, r.hw)
+            if part is not None:       # the resnet's last contraction left the column sums: no statistics pass over x
+                stats = torch.empty((inst, self.cfg.norm_groups, 2), dtype=torch.float32, device=self.device)
+                ops.groupnorm_fold_linear_tile_sums(part, p["norm"].g, p["norm"].b, p["pin"].w, p["pin"].bias, w_f, b_f,
+                                                    instances=inst, rows=r.hw, c=c, groups=self.cfg.norm_groups,
+                                                    eps=p["norm"].eps, n=c, stats=stats)
+            else:
+                ops.groupnorm_fold_linear(x, p["norm"].g, p["norm"].b, p["pin"].w, p["pin"].bias, w_f, b_f, instances=inst,
+                                          rows=r.hw, c=c, groups=self.cfg.norm_groups, eps=p["norm"].eps, n=c, ws=r.gn_ws,
+                                          ldx=x.stride(0))
             return self._gemm(r, p["pin"], x, ln_next=p["s_attn"]["qkv"], w_groups=(w_f, b_f, r.hw))
         t = self._gn(r, p["norm"], x, temporal=False, silu=False)
         return self._gemm(r, p["pin"], t, ln_next=p["s_attn"]["qkv"])
@@ -559,7 +581,7 @@ class SVDUNetHIP:
             out._row_ln_stats = (st_next, ln_next.ln_eps, out.data_ptr(), _version(out), tuple(out.shape))
         return out
 
-    def _run_transformer(self, r: _Run, p, x, out=None):
+    def _run_transformer(self, r: _Run, p, x, out=None, gn_next=False):
         c, a = p["c"], p["alpha"]
         hs = self._proj_in(r, p, x)
         # --- spatial block
@@ -578,7 +600,7 @@ class SVDUNetHIP:
         # temporal out = ff(..)+ht1 ; blend = a*hs_s + (1-a)*temporal out   (folded into the epilogue)
         mix = self._ff_pair(r, p["t_ff1"], p["t_ff2"], ht1, self._ln_stats(p["t_ff1"], ht1), oscale=1.0 - a, res1=ht1,
                             r1scale=1.0 - a, res2=hs_s, r2scale=a)
-        return self._gemm(r, p["pout"], mix, res1=x, r1scale=1.0, out=out)
+        return self._gemm(r, p["pout"], mix, res1=x, r1scale=1.0, out=out, gn_next=gn_next)
 
     # ------------------------------------------------------------------ forward
     def forward_rows(self, x_rows, *, b, frames, h, w, t_value, ctx16, added_ids32, euler=None):
@@ -644,19 +666,20 @@ class SVDUNetHIP:
             return cats[-1][:, cx:]
 
         geom, _, _ = self._conv_geom(r)
-        x = self._gemm(r, self.conv_in, x_rows, conv=geom, out=skip_dest(r.m, self.conv_in.n_true))
+        x = self._gemm(r, self.conv_in, x_rows, conv=geom, out=skip_dest(r.m, self.conv_in.n_true), gn_next=True)
         for res, att, ds in self.down:
             for j, p in enumerate(res):
                 if att:
-                    x = self._run_resblock(r, p, x)
-                    x = self._run_transformer(r, att[j], x, out=skip_dest(r.m, p["cout"]))
+                    x = self._run_resblock(r, p, x, gn_next=True)          # -> the transformer's entry norm
+                    # -> the next resnet's norm1 (the level's last transformer feeds the downsampler: no norm)
+                    x = self._run_transformer(r, att[j], x, out=skip_dest(r.m, p["cout"]), gn_next=j + 1 < len(res))
                 else:
                     x = self._run_resblock(r, p, x, out=skip_dest(r.m, p["cout"]))
             if ds is not None:
                 geom, ho, wo = self._conv_geom(r, stride=2)
                 m_out = r.b * r.f * ho * wo
-                x = self._gemm(r, ds, x, m=m_out, conv=geom, out=skip_dest(m_out, ds.n_true))
-                r.h, r.w = ho, wo
+                r.h, r.w = ho, wo                    # (the output's level decides whether its frames are whole tiles)
+                x = self._gemm(r, ds, x, m=m_out, conv=geom, out=skip_dest(m_out, ds.n_true), gn_next=True)
         if len(cats) != len(cx_pop):
             raise RuntimeError("skip bookkeeping out of step with the up blocks")
 
@@ -671,8 +694,10 @@ class SVDUNetHIP:
                 cat = cats.pop()               # both halves are in place
                 last = j == len(res) - 1 and us is not None
                 if att:
-                    x = self._run_resblock(r, p, cat)
-                    x = self._run_transformer(r, att[j], x, out=None if last else x_dest())
+                    x = self._run_resblock(r, p, cat, gn_next=True)        # -> the transformer's entry norm
+                    # (an up resnet normalises the concatenation [x | skip]: no sums from one producer; the very last
+                    # transformer feeds conv_norm_out)
+                    x = self._run_transformer(r, att[j], x, out=None if last else x_dest(), gn_next=not cats and us is None)
                 else:
                     x = self._run_resblock(r, p, cat, out=None if last else x_dest())
                 del cat
