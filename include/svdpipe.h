@@ -185,6 +185,12 @@ int sp_groupnorm_ld_f16(const void *x, int64_t ldx, const float *gamma, const fl
 int sp_groupnorm_tile_sums_f16(const void *x, int64_t ldx, const float *part, const float *gamma, const float *beta, void *y,
                                int instances, int64_t rows, int c, int groups, float eps, int fuse_silu, float *stats,
                                void *stream);
+/* The same for a tensor that is the CONCATENATION [a | b] of two producers' outputs (an up block's resnet normalises
+ * [hidden | skip]): channels [0, c_a) are summed in `part` (row pitch c_a), channels [c_a, c) in `part_b` (row pitch c - c_a);
+ * per-column sums are additive, so a group may straddle the seam. */
+int sp_groupnorm_tile_sums2_f16(const void *x, int64_t ldx, const float *part, int c_a, const float *part_b, const float *gamma,
+                                const float *beta, void *y, int instances, int64_t rows, int c, int groups, float eps,
+                                int fuse_silu, float *stats, void *stream);
 /* sp_groupnorm_fold_linear_f16 (below) with the statistics folded from such column sums instead of a pass over x. */
 int sp_groupnorm_fold_linear_tile_sums_f16(const float *part, const float *gamma, const float *beta, int instances, int64_t rows,
                                            int c, int groups, float eps, const void *w, const float *bias, int n, void *w_out,

@@ -466,6 +466,35 @@ def test_groupnorm_statistics_from_the_producing_contraction(mode, inst, rows, c
                                 eps=1e-6, silu=True, stats=stats)
 
 
+@pytest.mark.parametrize("na,nb", [(640, 320), (320, 320), (256, 512)])
+def test_groupnorm_statistics_of_a_concatenation_from_two_producers(na, nb):
+    """An up block's resnet normalises [hidden | skip]: two contractions write the two column ranges of one buffer, each
+    leaves its column sums, and sp_groupnorm_tile_sums2_f16 folds both (per-column sums are additive, so the 30-channel
+    groups of a 640 + 320 concatenation may straddle the seam) -- against F.group_norm of the buffer in fp64."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(na + nb)
+    inst, rows, cin = 2, 512, 128
+    m, c = inst * rows, na + nb
+    cat = torch.empty(m, c, dtype=torch.float16, device=DEV)
+    parts = []
+    for n, col0, with_res in ((na, 0, True), (nb, na, False)):
+        a = torch.randn(m, cin, generator=g).half().to(DEV)
+        w = (torch.randn(n, cin, generator=g) / math.sqrt(cin)).half().to(DEV)
+        bias = (torch.randn(n, generator=g) * 2.0).to(DEV)
+        part = torch.empty(m // 256, 2, n, 2, dtype=torch.float32, device=DEV)
+        kw = dict(res1=torch.randn(m, n, generator=g).half().to(DEV), r1scale=1.0) if with_res else {}
+        ops.gemm(a, w, cat[:, col0:col0 + n], m=m, n=n, cin=cin, bias=bias, ldd=c, gn_part=part, **kw)
+        parts.append(part)
+    gamma, beta = 1.0 + 0.3 * torch.randn(c, generator=g), torch.randn(c, generator=g)
+    y = torch.empty(m, c, dtype=torch.float16, device=DEV)
+    stats = torch.empty(inst * 32 * 2, dtype=torch.float32, device=DEV)
+    ops.groupnorm_tile_sums(cat, parts[0], gamma.to(DEV), beta.to(DEV), y, instances=inst, rows=rows, c=c, groups=32, eps=1e-6,
+                            silu=True, stats=stats, part_b=parts[1], c_a=na)
+    ref = F.silu(F.group_norm(cat.double().cpu().reshape(inst, rows, c).permute(0, 2, 1), 32, gamma.double(), beta.double(),
+                              eps=1e-6)).permute(0, 2, 1).reshape(m, c).float()
+    check(y, ref, l2=2e-3, mx=2e-2)
+
+
 def test_gemm_rejects_row_groups_that_tiles_would_straddle():
     ops = _ops()
     a = torch.zeros(640, 320, dtype=torch.float16, device=DEV)

@@ -294,10 +294,21 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &p, f32x4 (&acc)[TN][
         const int half = grp / RG, sub = grp - half * RG;
         const int r0 = half * 128 + sub * RPG, r1 = min(r0 + RPG, half * 128 + 128);
         const int col = quad * 4;
-        for (int r = r0; r < r1; ++r) {
-          const f16x4 v = *(const f16x4 *)(smem + r * (bno * 2) + ((((col >> 3) ^ (r & 7))) << 4) + (col & 4) * 2);
+        // eight independent LDS reads in flight per pass (a one-read-at-a-time loop is 43 exposed round trips); rows past
+        // the group's end re-read its last row with weight zero
+        for (int k = 0; k < RPG; k += 8) {
+          f16x4 v[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const float f = (float)v[e]; sm[e] += f; sq[e] = fmaf(f, f, sq[e]); }
+          for (int u = 0; u < 8; ++u) {
+            const int r = min(r0 + k + u, r1 - 1);
+            v[u] = *(const f16x4 *)(smem + r * (bno * 2) + ((((col >> 3) ^ (r & 7))) << 4) + (col & 4) * 2);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float wgt = r0 + k + u < r1 ? 1.0f : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float f = (float)v[u][e] * wgt; sm[e] += f; sq[e] = fmaf(f, f, sq[e]); }
+          }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // the tile has been read: its memory takes the partials

@@ -579,9 +579,13 @@ __global__ __launch_bounds__(256) void ln_stats_rows_kernel(const f16 *__restric
 // [tile][half][c][2], 256-row tiles): one block per (instance, group) adds its tiles x halves x channels in a FIXED order
 // (thread t takes every 256th entry, lane 0 of wave 0 folds the 256 partials) in fp64 -- sums of un-shifted values, so the
 // cancellation of E[x^2] - mean^2 is left to the 53-bit fold (the per-tile sums are fp32 over 128 rows each).
+// part_b != null: the normalised tensor is the CONCATENATION [a | b] of two producers' outputs (an up block's resnet reads
+// [hidden | skip]): channels [0, c_a) come from part (row pitch c_a), channels [c_a, c) from part_b (row pitch c - c_a) --
+// per-column sums are additive, so a group may straddle the seam.
 __global__ __launch_bounds__(256) void gn_tile_sums_finalize_kernel(const float *__restrict__ part, float *__restrict__ stats,
                                                                    int tiles_per_inst, int c, int groups, int64_t rows,
-                                                                   float eps) {
+                                                                   float eps, const float *__restrict__ part_b = nullptr,
+                                                                   int c_a = 0) {
   __shared__ double red[256 * 2];
   const int inst = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
   const int cpg = c / groups;
@@ -591,7 +595,10 @@ __global__ __launch_bounds__(256) void gn_tile_sums_finalize_kernel(const float 
   for (int e = tid; e < total; e += 256) {
     const int t = e / per_tile, r = e - t * per_tile;
     const int half = r / cpg, ch = g * cpg + (r - half * cpg);
-    const float2 v = *(const float2 *)(part + ((((int64_t)inst * tiles_per_inst + t) * 2 + half) * c + ch) * 2);
+    const int64_t rec = ((int64_t)inst * tiles_per_inst + t) * 2 + half;
+    const float2 v = !part_b ? *(const float2 *)(part + (rec * c + ch) * 2)
+                     : ch < c_a ? *(const float2 *)(part + (rec * c_a + ch) * 2)
+                                : *(const float2 *)(part_b + (rec * (c - c_a) + (ch - c_a)) * 2);
     a += (double)v.x; b += (double)v.y;
   }
   red[tid * 2] = a; red[tid * 2 + 1] = b;
@@ -608,10 +615,23 @@ __global__ __launch_bounds__(256) void gn_tile_sums_finalize_kernel(const float 
 
 }  // namespace
 
+extern "C" int sp_groupnorm_tile_sums2_f16(const void *x, int64_t ldx, const float *part, int c_a, const float *part_b,
+                                           const float *gamma, const float *beta, void *y, int instances, int64_t rows, int c,
+                                           int groups, float eps, int fuse_silu, float *stats, void *stream);
+
 extern "C" int sp_groupnorm_tile_sums_f16(const void *x, int64_t ldx, const float *part, const float *gamma, const float *beta,
                                           void *y, int instances, int64_t rows, int c, int groups, float eps, int fuse_silu,
                                           float *stats, void *stream) {
+  return sp_groupnorm_tile_sums2_f16(x, ldx, part, c, nullptr, gamma, beta, y, instances, rows, c, groups, eps, fuse_silu, stats,
+                                     stream);
+}
+
+extern "C" int sp_groupnorm_tile_sums2_f16(const void *x, int64_t ldx, const float *part, int c_a, const float *part_b,
+                                           const float *gamma, const float *beta, void *y, int instances, int64_t rows, int c,
+                                           int groups, float eps, int fuse_silu, float *stats, void *stream) {
   SP_REQUIRE(x && y && part && stats, "sp_groupnorm_tile_sums_f16: null pointer");
+  SP_REQUIRE(part_b ? (c_a > 0 && c_a < c && c_a % 4 == 0 && (c - c_a) % 4 == 0) : c_a == c,
+             "sp_groupnorm_tile_sums_f16: c_a=%d invalid for C=%d", c_a, c);
   SP_REQUIRE(ldx >= c && ldx % 8 == 0, "sp_groupnorm_tile_sums_f16: ldx=%lld must be a multiple of 8 and >= C=%d", (long long)ldx, c);
   SP_REQUIRE(instances > 0 && rows > 0 && rows % 256 == 0 && rows / 256 <= 0x7fffffff,
              "sp_groupnorm_tile_sums_f16: an instance must be a whole number of 256-row tiles (rows=%lld)", (long long)rows);
@@ -624,7 +644,7 @@ extern "C" int sp_groupnorm_tile_sums_f16(const void *x, int64_t ldx, const floa
   hipStream_t s = (hipStream_t)stream;
   SP_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(gn_tile_sums_finalize_kernel, dim3(instances, groups), dim3(256), 0, s, part, stats, (int)(rows / 256), c,
-                     groups, rows, eps);
+                     groups, rows, eps, part_b, c_a);
   SP_CHECK_LAUNCH("sp_groupnorm_tile_sums_f16(finalize)");
   int64_t blocks_y = (2048 + instances - 1) / instances;
   int64_t maxb = (rows + 16 * P - 1) / (16 * P);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "sp_groupnorm_f16": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _Z, _P]),
     "sp_groupnorm_ld_f16": (_I, [_P, _L, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _Z, _P]),
     "sp_groupnorm_tile_sums_f16": (_I, [_P, _L, _P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _P]),
+    "sp_groupnorm_tile_sums2_f16": (_I, [_P, _L, _P, _I, _P, _P, _P, _P, _I, _L, _I, _I, _F, _I, _P, _P]),
     "sp_groupnorm_fold_linear_tile_sums_f16": (_I, [_P, _P, _P, _I, _L, _I, _I, _F, _P, _P, _I, _P, _P, _P, _P]),
     "sp_groupnorm_fold_linear_f16": (_I, [_P, _L, _P, _P, _I, _L, _I, _I, _F, _P, _P, _I, _P, _P, _P, _Z, _P]),
     "sp_layernorm_f16": (_I, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _F, _P]),

@@ -193,14 +193,17 @@ def groupnorm(x, gamma, beta, y, *, instances, rows, c, groups, eps, silu, ws, l
     return y
 
 
-def groupnorm_tile_sums(x, part, gamma, beta, y, *, instances, rows, c, groups, eps, silu, stats, ldx=None):
+def groupnorm_tile_sums(x, part, gamma, beta, y, *, instances, rows, c, groups, eps, silu, stats, ldx=None, part_b=None,
+                        c_a=None):
     """GroupNorm(+SiLU) of ``x`` from the per-tile column sums its producing contraction left in ``part``
-    (``gemm(..., gn_part=part)``): no statistics pass over ``x`` (``sp_groupnorm_tile_sums_f16``)."""
+    (``gemm(..., gn_part=part)``): no statistics pass over ``x`` (``sp_groupnorm_tile_sums_f16``).  ``part_b`` / ``c_a``: x is
+    the concatenation of two producers' outputs, channels ``[0, c_a)`` summed in ``part``, the rest in ``part_b``."""
     ldx = int(ldx if ldx is not None else x.stride(0))
     with _Timed("groupnorm", 0.0, 2 * 2.0 * instances * rows * c):
-        _check(load().sp_groupnorm_tile_sums_f16(_f16(x, "x").data_ptr(), ldx, part.data_ptr(), _ptr(gamma), _ptr(beta),
-                                                 _f16(y, "y").data_ptr(), instances, rows, c, groups, float(eps), int(silu),
-                                                 stats.data_ptr(), _stream()), "sp_groupnorm_tile_sums_f16")
+        _check(load().sp_groupnorm_tile_sums2_f16(_f16(x, "x").data_ptr(), ldx, part.data_ptr(), int(c_a if part_b is not None else c),
+                                                  _ptr(part_b), _ptr(gamma), _ptr(beta), _f16(y, "y").data_ptr(), instances, rows,
+                                                  c, groups, float(eps), int(silu), stats.data_ptr(), _stream()),
+               "sp_groupnorm_tile_sums2_f16")
     return y
 
 

@@ -438,10 +438,20 @@ class SVDUNetHIP:
             return have[0]
         return None
 
-    def _gn(self, r: _Run, norm: _Norm, x, *, temporal: bool, silu: bool):
+    def _gn(self, r: _Run, norm: _Norm, x, *, temporal: bool, silu: bool, concat_sums=None):
+        """``concat_sums`` = (sums of the left columns, sums of the right columns): x is a concatenation buffer whose two
+        halves were written by two contractions that both left their column sums (an up block's first norm)."""
         c = x.shape[1]
         inst, rows = (r.b, r.f * r.hw) if temporal else (r.b * r.f, r.hw)
         y = self._buf(x.shape[0], c)
+        if concat_sums is not None and concat_sums[0] is not None and concat_sums[1] is not None and rows % 256 == 0:
+            (pa, _pa, _va, sa), (pb, _pb, _vb, sb) = concat_sums
+            if (sa[0] == x.shape[0] == sb[0] and sa[1] + sb[1] == c and x.stride(0) == c and _pa == x.data_ptr()
+                    and _pb == x.data_ptr() + 2 * sa[1] and _va == _version(x) == _vb):
+                stats = torch.empty((inst, self.cfg.norm_groups, 2), dtype=torch.float32, device=self.device)
+                ops.groupnorm_tile_sums(x, pa, norm.g, norm.b, y, instances=inst, rows=rows, c=c, groups=self.cfg.norm_groups,
+                                        eps=norm.eps, silu=silu, stats=stats, ldx=c, part_b=pb, c_a=sa[1])
+                return y
         part = self._tile_sums(x, rows)
         if part is not None:
             stats = torch.empty((inst, self.cfg.norm_groups, 2), dtype=torch.float32, device=self.device)
@@ -463,12 +473,12 @@ class SVDUNetHIP:
         return (r.b * r.f, r.h, r.w, ho, wo, stride, ups), ho, wo
 
     # ------------------------------------------------------------------ blocks
-    def _run_resblock(self, r: _Run, p, x, out=None, gn_next=False):
+    def _run_resblock(self, r: _Run, p, x, out=None, gn_next=False, concat_sums=None):
         """``out``: where the block's result goes (a half of a concatenation buffer), default a fresh tensor.
         ``gn_next``: the result goes straight into a GroupNorm (a transformer's entry norm, ``conv_norm_out``): ask the last
         contraction for the column sums."""
         geom, _, _ = self._conv_geom(r)
-        t = self._gn(r, p["n1"], x, temporal=False, silu=True)
+        t = self._gn(r, p["n1"], x, temporal=False, silu=True, concat_sums=concat_sums)
         n1 = p["c1"].n
         t = self._gemm(r, p["c1"], t, conv=geom, bias2=r.temb[p["te_s"]:p["te_s"] + n1], bias2_rows=r.m, gn_next=True)
         t = self._gn(r, p["n2"], t, temporal=False, silu=True)
@@ -659,27 +669,38 @@ class SVDUNetHIP:
         # working on the skip through its strided view.
         cx_pop = [p["cx"] for res, _, _ in self.up for p in res]           # in the order the up path consumes skips
         cats = []                                                          # in the order the down path produces them
+        cat_sums = []                                                      # per buffer: column sums of its [left, right] halves
 
         def skip_dest(rows, cskip):
             cx = cx_pop[len(cx_pop) - 1 - len(cats)]
             cats.append(self._buf(rows, cx + cskip))
+            cat_sums.append([None, None])
             return cats[-1][:, cx:]
 
+        def note_skip(t):                      # the skip's producer may have left its column sums beside the view it wrote
+            cat_sums[-1][1] = getattr(t, "_gn_tile_sums", None)
+            return t
+
+        def note_x(t):                         # ... and so may the producer of the running tensor's half
+            if cats and t is not None:
+                cat_sums[-1][0] = getattr(t, "_gn_tile_sums", None)
+            return t
+
         geom, _, _ = self._conv_geom(r)
-        x = self._gemm(r, self.conv_in, x_rows, conv=geom, out=skip_dest(r.m, self.conv_in.n_true), gn_next=True)
+        x = note_skip(self._gemm(r, self.conv_in, x_rows, conv=geom, out=skip_dest(r.m, self.conv_in.n_true), gn_next=True))
         for res, att, ds in self.down:
             for j, p in enumerate(res):
                 if att:
                     x = self._run_resblock(r, p, x, gn_next=True)          # -> the transformer's entry norm
-                    # -> the next resnet's norm1 (the level's last transformer feeds the downsampler: no norm)
-                    x = self._run_transformer(r, att[j], x, out=skip_dest(r.m, p["cout"]), gn_next=j + 1 < len(res))
+                    # -> the next resnet's norm1, and (as a skip) the first norm of an up resnet
+                    x = note_skip(self._run_transformer(r, att[j], x, out=skip_dest(r.m, p["cout"]), gn_next=True))
                 else:
-                    x = self._run_resblock(r, p, x, out=skip_dest(r.m, p["cout"]))
+                    x = note_skip(self._run_resblock(r, p, x, out=skip_dest(r.m, p["cout"]), gn_next=True))
             if ds is not None:
                 geom, ho, wo = self._conv_geom(r, stride=2)
                 m_out = r.b * r.f * ho * wo
                 r.h, r.w = ho, wo                    # (the output's level decides whether its frames are whole tiles)
-                x = self._gemm(r, ds, x, m=m_out, conv=geom, out=skip_dest(m_out, ds.n_true), gn_next=True)
+                x = note_skip(self._gemm(r, ds, x, m=m_out, conv=geom, out=skip_dest(m_out, ds.n_true), gn_next=True))
         if len(cats) != len(cx_pop):
             raise RuntimeError("skip bookkeeping out of step with the up blocks")
 
@@ -688,23 +709,25 @@ class SVDUNetHIP:
 
         x = self._run_resblock(r, self.mid[0], x)
         x = self._run_transformer(r, self.mid[1], x)
-        self._run_resblock(r, self.mid[2], x, out=x_dest())
+        note_x(self._run_resblock(r, self.mid[2], x, out=x_dest(), gn_next=True))
         for res, att, us in self.up:
             for j, p in enumerate(res):
                 cat = cats.pop()               # both halves are in place
+                sums = cat_sums.pop()          # ... and, where both producers left them, the column sums of both
                 last = j == len(res) - 1 and us is not None
                 if att:
-                    x = self._run_resblock(r, p, cat, gn_next=True)        # -> the transformer's entry norm
-                    # (an up resnet normalises the concatenation [x | skip]: no sums from one producer; the very last
-                    # transformer feeds conv_norm_out)
-                    x = self._run_transformer(r, att[j], x, out=None if last else x_dest(), gn_next=not cats and us is None)
+                    x = self._run_resblock(r, p, cat, gn_next=True, concat_sums=sums)   # -> the transformer's entry norm
+                    # -> the left half of the next up resnet's input, or conv_norm_out at the very end
+                    x = note_x(self._run_transformer(r, att[j], x, out=None if last else x_dest(), gn_next=not last))
                 else:
-                    x = self._run_resblock(r, p, cat, out=None if last else x_dest())
+                    x = note_x(self._run_resblock(r, p, cat, out=None if last else x_dest(), gn_next=not last,
+                                                  concat_sums=sums))
                 del cat
             if us is not None:
                 geom, ho, wo = self._conv_geom(r, ups=1)
-                x = self._gemm(r, us, x, m=r.b * r.f * ho * wo, conv=geom, out=x_dest())
-                r.h, r.w = ho, wo
+                m_up = r.b * r.f * ho * wo
+                r.h, r.w = ho, wo                    # (the output's level decides whether its frames are whole tiles)
+                x = note_x(self._gemm(r, us, x, m=m_up, conv=geom, out=x_dest(), gn_next=True))
         x = self._gn(r, self.norm_out, x, temporal=False, silu=True)
         geom, _, _ = self._conv_geom(r)
         if euler is not None:
