@@ -588,24 +588,32 @@ __global__ __launch_bounds__(256) void gn_tile_sums_finalize_kernel(const float 
                                                                    int c_a = 0) {
   __shared__ double red[256 * 2];
   const int inst = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
-  const int cpg = c / groups;
-  const int per_tile = 2 * cpg;                                   // (half, channel) entries of this group per tile
-  const int total = tiles_per_inst * per_tile;
+  const int cpg = c / groups, ch0 = g * cpg;
   double a = 0.0, b = 0.0;
-  for (int e = tid; e < total; e += 256) {
-    const int t = e / per_tile, r = e - t * per_tile;
-    const int half = r / cpg, ch = g * cpg + (r - half * cpg);
-    const int64_t rec = ((int64_t)inst * tiles_per_inst + t) * 2 + half;
-    const float2 v = !part_b ? *(const float2 *)(part + (rec * c + ch) * 2)
-                     : ch < c_a ? *(const float2 *)(part + (rec * c_a + ch) * 2)
-                                : *(const float2 *)(part_b + (rec * (c - c_a) + (ch - c_a)) * 2);
-    a += (double)v.x; b += (double)v.y;
+  // thread t takes the (tile, half) records t, t + 256, ...: the group's cpg (sum, sum of squares) pairs of a record are
+  // contiguous (8 bytes each), every load of a thread is independent -- no index arithmetic beyond one multiply per record
+  for (int rec = tid; rec < 2 * tiles_per_inst; rec += 256) {
+    const int64_t r = (int64_t)inst * tiles_per_inst * 2 + rec;
+    float sa = 0.f, sb = 0.f;
+    if (!part_b) {
+      const float2 *src = (const float2 *)(part + (r * c + ch0) * 2);
+      for (int k = 0; k < cpg; ++k) { const float2 v = src[k]; sa += v.x; sb += v.y; }
+    } else {
+      for (int k = 0; k < cpg; ++k) {
+        const int ch = ch0 + k;
+        const float2 v = ch < c_a ? *(const float2 *)(part + (r * c_a + ch) * 2)
+                                  : *(const float2 *)(part_b + (r * (c - c_a) + (ch - c_a)) * 2);
+        sa += v.x; sb += v.y;
+      }
+    }
+    a += (double)sa; b += (double)sb;          // (fp32 over one record's <= 128 channels-times-rows sums, fp64 across records)
   }
   red[tid * 2] = a; red[tid * 2 + 1] = b;
   __syncthreads();
   if (tid == 0) {
     a = 0.0; b = 0.0;
-    for (int q = 0; q < 256; ++q) { a += red[q * 2]; b += red[q * 2 + 1]; }
+    const int n = 2 * tiles_per_inst < 256 ? 2 * tiles_per_inst : 256;
+    for (int q = 0; q < n; ++q) { a += red[q * 2]; b += red[q * 2 + 1]; }
     const double cnt = (double)rows * cpg, mean = a / cnt;
     double var = b / cnt - mean * mean; if (var < 0.0) var = 0.0;
     stats[((int64_t)inst * groups + g) * 2] = (float)mean;

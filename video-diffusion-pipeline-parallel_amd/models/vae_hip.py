@@ -202,6 +202,7 @@ class _VAEKernels:
         # mid-block attention logits in fp32 wherever the token count allows (a multiple of 256); VDPP_VAE_FP16_SCORES=1
         # selects the round-3 composition with fp16 scores everywhere (A/B, tests)
         self.fp32_scores = __import__("os").environ.get("VDPP_VAE_FP16_SCORES") != "1"
+        self.gn_from_epilogue = __import__("os").environ.get("VDPP_GN_EPILOGUE", "1") != "0"
         return dev
 
     def _attn(self, sd, p, c):
@@ -214,17 +215,35 @@ class _VAEKernels:
     def _buf(self, rows, c):
         return torch.empty((rows, c), dtype=torch.float16, device=self.device)
 
-    def _gemm(self, layer: _Dense, a, m, *, conv=None, temporal=None, **kw):
+    def _gemm(self, layer: _Dense, a, m, *, conv=None, temporal=None, gn_rows=0, **kw):
+        """``gn_rows`` > 0: the output goes straight into a GroupNorm whose instances are multiples of that many rows (a
+        frame): where the tiles allow it (256- / 320-wide column tiles, whole 256-row tiles per frame) the epilogue leaves
+        per-tile column sums beside the output and ``_gn`` folds them instead of reading the tensor again (round 5,
+        ``sp_gemm_desc.gn_part``; the 128-channel level has no such tiles)."""
         out = kw.pop("out", None)
         if out is None:
             out = self._buf(m, layer.n_true)
         n_store = layer.n_true if layer.n_true != layer.n else 0
+        part = None
+        if (gn_rows and self.gn_from_epilogue and gn_rows % 256 == 0 and m % 256 == 0 and n_store == 0
+                and (layer.n % 256 == 0 or layer.n % 320 == 0)):
+            part = torch.empty((m // 256, 2, layer.n, 2), dtype=torch.float32, device=self.device)
+            kw.update(gn_part=part)
         ops.gemm(a, layer.w, out, m=m, n=layer.n, cin=layer.cin, mode=layer.mode, conv=conv, temporal=temporal,
                  bias=layer.bias, n_store=n_store, ldd=layer.n_true, lda=a.shape[1], **kw)
+        if part is not None:
+            out._gn_tile_sums = (part, out.data_ptr(), tuple(out.shape))
         return out
 
     def _gn(self, norm: _Norm, x, inst, rows, silu):
         c = x.shape[1]
+        have = getattr(x, "_gn_tile_sums", None)
+        if have is not None and have[1] == x.data_ptr() and have[2] == tuple(x.shape) and rows % 256 == 0:
+            y = self._buf(x.shape[0], c)
+            stats = torch.empty((inst, self.cfg.norm_groups, 2), dtype=torch.float32, device=self.device)
+            ops.groupnorm_tile_sums(x, have[0], norm.g, norm.b, y, instances=inst, rows=rows, c=c, groups=self.cfg.norm_groups,
+                                    eps=norm.eps, silu=silu, stats=stats)
+            return y
         need = ops.groupnorm_ws_bytes(inst, rows, c, self.cfg.norm_groups)
         key = torch.cuda.current_stream(self.device).cuda_stream
         ws = self._ws.get(key)
@@ -270,7 +289,7 @@ class _VAEKernels:
                 ops.gemm(scores, vt, o[r], m=hw, n=c, cin=hw, bias=p["bv"])                # O = P V + b_v
             del scores
         del vt, q, k, t
-        return self._gemm(p["out"], o, m, res1=x, r1scale=1.0)
+        return self._gemm(p["out"], o, m, res1=x, r1scale=1.0, gn_rows=hw)
 
 
 class TemporalDecoderHIP(_VAEKernels):
@@ -318,22 +337,23 @@ class TemporalDecoderHIP(_VAEKernels):
                     tn2=_Norm(sd, t + ".norm2", dev, 1e-5), tc2=_Dense.tconv(sd, t + ".conv2", dev))
 
     # ------------------------------------------------------------------ blocks
-    def _run_res(self, p, x, b, f, h, w):
+    def _run_res(self, p, x, b, f, h, w, gn_next=True):
         """SpatioTemporalResBlock(temb_channels=None): ResnetBlock2D per frame, TemporalResnetBlock over the frames,
         blended by the (switched) AlphaBlender."""
         hw, m = h * w, b * f * h * w
         geom = (b * f, h, w, h, w, 1, 0)
         t = self._gn(p["n1"], x, b * f, hw, True)
-        t = self._gemm(p["c1"], t, m, conv=geom)
+        t = self._gemm(p["c1"], t, m, conv=geom, gn_rows=hw)
         t = self._gn(p["n2"], t, b * f, hw, True)
         skip = x if p["sc"] is None else self._gemm(p["sc"], x, m)
-        s = self._gemm(p["c2"], t, m, conv=geom, res1=skip, r1scale=1.0)
+        s = self._gemm(p["c2"], t, m, conv=geom, res1=skip, r1scale=1.0, gn_rows=hw)
         del t, skip
         t = self._gn(p["tn1"], s, b, f * hw, True)
-        t = self._gemm(p["tc1"], t, m, temporal=(f, hw))
+        t = self._gemm(p["tc1"], t, m, temporal=(f, hw), gn_rows=hw)
         t = self._gn(p["tn2"], t, b, f * hw, True)
         # (1-sig)*s + sig*(s + conv2(t)) = s + sig*conv2(t)
-        return self._gemm(p["tc2"], t, m, temporal=(f, hw), oscale=p["temporal_weight"], res1=s, r1scale=1.0)
+        return self._gemm(p["tc2"], t, m, temporal=(f, hw), oscale=p["temporal_weight"], res1=s, r1scale=1.0,
+                          gn_rows=hw if gn_next else 0)
 
     # ------------------------------------------------------------------ public
     def _decode_chunk(self, src, src_strides, dst, dst_strides, *, flat0, n, frames_per_item, batch, frames, h, w,
@@ -345,15 +365,16 @@ class TemporalDecoderHIP(_VAEKernels):
                             strides=src_strides, h=h, w=w, cpad=self.conv_in.cin)
         b, f = batch, frames
         m = n * h * w
-        x = self._gemm(self.conv_in, rows, m, conv=(n, h, w, h, w, 1, 0))
+        x = self._gemm(self.conv_in, rows, m, conv=(n, h, w, h, w, 1, 0), gn_rows=h * w)
         x = self._run_res(self.mid[0], x, b, f, h, w)
         x = self._run_attn(self.mid[1], x, n, h * w)
         x = self._run_res(self.mid[2], x, b, f, h, w)
         for res, us in self.up:
-            for p in res:
-                x = self._run_res(p, x, b, f, h, w)
+            for j, p in enumerate(res):
+                # (a level's last resnet feeds the upsampling convolution: no norm behind it)
+                x = self._run_res(p, x, b, f, h, w, gn_next=not (us is not None and j == len(res) - 1))
             if us is not None:
-                x = self._gemm(us, x, n * 4 * h * w, conv=(n, h, w, 2 * h, 2 * w, 1, 1))
+                x = self._gemm(us, x, n * 4 * h * w, conv=(n, h, w, 2 * h, 2 * w, 1, 1), gn_rows=4 * h * w)
                 h, w = 2 * h, 2 * w
         x = self._gn(self.norm_out, x, n, h * w, True)
         x = self._gemm(self.conv_out, x, n * h * w, conv=(n, h, w, h, w, 1, 0))
