@@ -792,6 +792,18 @@ def supervise_rank(args, argv):
             time.sleep(0.1)
         return None
 
+    def leave(status):
+        """Best-effort tidy-up of the rendezvous files (rank 0 last: the others only ever read files of finished attempts)."""
+        try:
+            if rank == 0:
+                time.sleep(1.0)
+                for name in os.listdir(rdv):
+                    os.unlink(os.path.join(rdv, name))
+                os.rmdir(rdv)
+        except OSError:
+            pass
+        return status
+
     history, rc = [], 1
     for k, rung in enumerate(ladder):
         env = dict(env0, VDPP_BENCH_WORKER="1", VDPP_BENCH_RUNG=rung["key"], VDPP_BENCH_ATTEMPT=str(k),
@@ -840,17 +852,17 @@ def supervise_rank(args, argv):
             v = wait_for(f"a{k}.r{r}.rc", limit + 90)
             rcs.append(int(v.split()[0]) if v is not None else -1)
         if all(v == 0 for v in rcs):
-            return 0
+            return leave(0)
         where = {str(r): (get(f"a{k}.r{r}.where") or "").strip() for r in range(world) if rcs[r] != 0}
         history.append({"attempt": k, "schedule": rung["schedule"], "transport": rung["transport"], "rc_per_rank": rcs,
                         "watchdog_where": where})
         if rank == 0:
             print(f"bench.py: attempt {k} ({rung['key']}) FAILED: exit status per rank {rcs}, {where}", file=sys.stderr, flush=True)
         if RC_USAGE in rcs:
-            return RC_USAGE
+            return leave(RC_USAGE)
         if rc == 0:
             rc = 6                                            # this rank was fine, the job was not
-    return rc
+    return leave(rc)
 
 
 def launch_ranks(args, argv):
