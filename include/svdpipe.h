@@ -121,6 +121,13 @@ typedef struct sp_gemm_desc {
      folded LayerNorm / ln_out / n_store / Euler tail; the call runs on the 256-row ping-pong tiles.  Sums
      are folded in a fixed order (bit-reproducible).  NULL = off. */
   float *gn_part;
+  /* Extra LINEAR tap (round 5): behind the taps of `mode` the contraction runs on over cin2 channels of a SECOND tensor a2
+     (fp16 [m][lda2], row i for output row i), multiplied with weight columns [taps*cin, taps*cin + cin2): w is then
+     [n][taps*cin + cin2].  A resnet's 1x1 shortcut convolution folded into its second 3x3 convolution
+     (conv2(h) + conv_shortcut(x) = one contraction with bias = b2 + b_sc): the skip tensor is neither written nor read.
+     cin2 a multiple of 64; runs on the 256-row ping-pong tiles (n a multiple of 256 or 320; no geglu / folded LayerNorm /
+     ln_out / n_store / Euler tail / per-group weights / split-K).  NULL = off. */
+  const void *a2; int64_t lda2; int cin2;
 } sp_gemm_desc;
 
 int sp_gemm_f16(const sp_gemm_desc *desc, void *stream);

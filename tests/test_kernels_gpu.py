@@ -495,6 +495,58 @@ def test_groupnorm_statistics_of_a_concatenation_from_two_producers(na, nb):
     check(y, ref, l2=2e-3, mx=2e-2)
 
 
+@pytest.mark.parametrize("mode,n,cin,cin2,pad", [(1, 320, 320, 640, 0), (1, 256, 128, 64, 64), (0, 640, 256, 960, 0), (2, 320, 64, 128, 0)])
+def test_gemm_extra_linear_tap(mode, n, cin, cin2, pad):
+    """sp_gemm_desc.a2: behind the taps of the convolution the contraction runs on over the channels of a SECOND tensor's
+    rows against the weight columns that follow -- conv2(h) + conv_shortcut(x) of a resnet as ONE call, against the two
+    torch operations in fp64; a2 as a column slice of a wider buffer (lda2 > cin2), ragged-free m of several tiles, with and
+    without the GroupNorm column sums of the result."""
+    ops = _ops()
+    from vdpp_amd.models import weights as W
+    g = torch.Generator().manual_seed(n + cin + cin2)
+    inst, hh, ww = 3, 16, 16
+    m = inst * hh * ww
+    x2 = h(torch.randn(m, cin2 + pad, generator=g))
+    wsc = h(torch.randn(n, cin2, generator=g) / math.sqrt(cin2))
+    bias = torch.randn(n, generator=g)
+    kw = {}
+    if mode == 1:
+        x = h(torch.randn(inst, hh, ww, cin, generator=g))
+        wc = h(torch.randn(n, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+        wp = W.pack_conv3x3(wc.half())
+        a = x.reshape(m, cin)
+        ref = F.conv2d(x.double().permute(0, 3, 1, 2), wc.double(), padding=1).permute(0, 2, 3, 1).reshape(m, n)
+        kw.update(mode=ops.A_CONV3X3, conv=(inst, hh, ww, hh, ww, 1, 0))
+    elif mode == 2:
+        a = h(torch.randn(m, cin, generator=g))
+        wt = h(torch.randn(n, cin, 3, 1, 1, generator=g) / math.sqrt(3 * cin))
+        wp = W.pack_tconv3(wt.half())
+        x5 = a.double().reshape(1, inst, hh * ww, cin).permute(0, 3, 1, 2)                  # (1, C, frames, pixels)
+        ref = F.conv2d(x5, wt.double()[:, :, :, 0, :], padding=(1, 0))[0].permute(1, 2, 0).reshape(m, n)
+        kw.update(mode=ops.A_TEMPORAL3, temporal=(inst, hh * ww))
+    else:
+        a = h(torch.randn(m, cin, generator=g))
+        wl = h(torch.randn(n, cin, generator=g) / math.sqrt(cin))
+        wp = wl.half()
+        ref = a.double() @ wl.double().t()
+    ref = (ref + x2[:, :cin2].double() @ wsc.double().t() + bias.double()).float()
+    wcat = torch.cat([wp, wsc.half()], dim=1).contiguous().to(DEV)
+    x2d = x2.half().to(DEV)
+    out = torch.empty(m, n, dtype=torch.float16, device=DEV)
+    ops.gemm(a.half().to(DEV), wcat, out, m=m, n=n, cin=cin, bias=bias.to(DEV), a2=x2d[:, :cin2], cin2=cin2, lda2=cin2 + pad, **kw)
+    check(out, ref)
+    part = torch.full((m // 256, 2, n, 2), float("nan"), dtype=torch.float32, device=DEV)
+    out2 = torch.empty_like(out)
+    ops.gemm(a.half().to(DEV), wcat, out2, m=m, n=n, cin=cin, bias=bias.to(DEV), a2=x2d[:, :cin2], cin2=cin2, lda2=cin2 + pad,
+             gn_part=part, **kw)
+    assert torch.equal(out2, out)
+    o64 = out.double().cpu().reshape(m // 128, 128, n)
+    got = part.double().cpu().reshape(m // 128, n, 2)
+    assert float((got[..., 0] - o64.sum(1)).abs().max()) <= 2e-3 * float(o64.abs().sum(1).max())
+    with pytest.raises(ops.HipKernelError, match="a2"):
+        ops.gemm(a.half().to(DEV), wcat, out, m=m, n=n, cin=cin, a2=x2d[:, :cin2], cin2=cin2 - 32, lda2=cin2 + pad, **kw)
+
+
 def test_gemm_rejects_row_groups_that_tiles_would_straddle():
     ops = _ops()
     a = torch.zeros(640, 320, dtype=torch.float16, device=DEV)

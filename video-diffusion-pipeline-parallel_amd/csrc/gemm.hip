@@ -514,7 +514,7 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
   // ---- output-row LayerNorm statistics live in the ping-pong epilogue (one tile = whole rows)
   // per-row-group weights: a tile must lie inside one group (192-row tiles need groups of a multiple of 192 rows, ...)
   auto group_ok = [&](int bm) { return a.w_group_rows == 0 || a.w_group_rows % bm == 0; };
-  if (a.gn_part)                               // per-tile column sums live in the ping-pong epilogue of 256-row tiles
+  if (a.gn_part || a.a2)                       // per-tile column sums / the extra linear tap live in the 256-row ping-pong tiles
     return launch_pp(a, 256, ok320 ? 320 : 256, s);
   if (a.ln_out) {
     const int bn = d->n <= 320 ? d->n : d->n / 2;
@@ -760,6 +760,19 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
   a.mode = d->mode; a.cin = d->cin;
   a.taps = d->mode == SP_A_CONV3X3 ? 9 : d->mode == SP_A_TEMPORAL3 ? 3 : 1;
   a.m = d->m; a.n = d->n; a.k = a.taps * d->cin;
+  a.a2 = nullptr; a.lda2 = 0; a.cin2 = 0;
+  if (d->a2) {
+    SP_REQUIRE(d->cin2 > 0 && d->cin2 % 64 == 0 && d->lda2 >= d->cin2 && d->lda2 % 8 == 0,
+               "sp_gemm_f16: a2 needs cin2 (%d) a positive multiple of 64 and lda2 (%lld) >= cin2, a multiple of 8", d->cin2,
+               (long long)d->lda2);
+    SP_REQUIRE(!d->geglu && !d->ln_stats && !d->ln_out && !d->euler_out && d->n_store == 0 && d->w_group_rows == 0 &&
+                   (d->n % 256 == 0 || d->n % 320 == 0) && !(d->gn_part && (d->res1 || d->res2)),
+               "sp_gemm_f16: a2 (extra linear tap) runs on the 256-row ping-pong tiles only: n a multiple of 256 or 320 (n = %d), "
+               "no geglu / folded LayerNorm / ln_out / n_store / Euler tail / per-group weights, gn_part only without residuals",
+               d->n);
+    a.a2 = (const f16 *)d->a2; a.lda2 = d->lda2; a.cin2 = d->cin2;
+    a.k += d->cin2;
+  }
   a.oscale = d->oscale; a.r1scale = d->r1scale; a.r2scale = d->r2scale;
   a.geglu = d->geglu; a.n_store = d->n_store;
   a.bias2_rows = d->bias2_rows > 0 ? d->bias2_rows : d->m;

@@ -13,6 +13,9 @@ __device__ __forceinline__ void wait_vm_lgkm() {
 
 struct GemmArgs {
   const f16 *a;
+  const f16 *a2;            // extra LINEAR tap behind the regular ones (sp_gemm_desc.a2): rows [m][lda2], cin2 channels
+  int64_t lda2;
+  int cin2;
   const f16 *w;
   const float *bias;
   const float *bias2;

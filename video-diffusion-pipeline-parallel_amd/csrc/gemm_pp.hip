@@ -373,6 +373,10 @@ template <int BM, int BN, int EXP>
 __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const GemmArgs p) {
   constexpr int PBM = BM;
   constexpr bool SPLITK = (EXP & 128) != 0;       // K-slice variant (only 256 x 256 is instantiated), see below
+  // Extra linear tap (EXP & 4096, its own instantiations): behind the taps of the convolution the K loop runs over the
+  // channels of a SECOND tensor's rows (same row index as the output) against the weight columns that follow -- a resnet's
+  // 1x1 shortcut convolution folded into its second 3x3 convolution: the skip tensor is neither written nor read
+  constexpr bool A2 = (EXP & 4096) != 0;
   constexpr int NWV = BM == 128 ? 4 : 8, NT = NWV * 64, WROWS = NWV / 4;   // waves, threads, wave rows (x 4 columns)
   constexpr int PSTAGES = pp_stages(BM, BN), PDIST = PSTAGES - 1;
   constexpr int TN = BN / 4 / 16;                 // weight sub-tiles per wave (4 or 5)
@@ -472,6 +476,19 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       int64_t row = -1;
+      if constexpr (A2) {
+        if (tap == p.taps) {                      // the extra tap: row m of a2 (wave-uniform branch)
+          const int r = (i * NWV + wave) * 16 + lrow;
+          if (a_in[i]) {
+            aptr[i] = p.a2 + ((int64_t)tile_m * PBM + r) * p.lda2 + schunk_a[i];
+            astep[i] = PBK;
+          } else {
+            aptr[i] = (const f16 *)(p.zero + lchunk * 16);
+            astep[i] = 0;
+          }
+          continue;
+        }
+      }
 #ifdef SP_GEMM_EXPERIMENTS
       // (EXP & 8, timing only: taps > 0 read the zero page = what an LDS-resident halo tile would save the memory pipe)
       if (a_in[i] && !((EXP & 8) && tap > 0)) {
@@ -564,7 +581,8 @@ __global__ __launch_bounds__(BM == 128 ? 256 : 512, 2) void gemm_pp_kernel(const
 
   int staged = 0, in_tap = 0, tap = 0, stage_slot = 0, read_slot = 0;
   auto stage_next = [&]() {
-    if (in_tap == cpt) { ++tap; in_tap = 0; set_tap(tap); }
+    // (the extra tap, index p.taps, is the last one and may be longer than a regular tap: no further switch behind it)
+    if (in_tap == cpt && (!A2 || tap < p.taps)) { ++tap; in_tap = 0; set_tap(tap); }
 #ifdef SP_GEMM_EXPERIMENTS
     if constexpr ((EXP & 16) != 0) skip_a = tap > 0;
 #endif
@@ -778,6 +796,7 @@ int launch_pp(GemmArgs &a, int bm, int bn, hipStream_t s) {
   // GroupNorm column sums of an output that residuals are added to: the copy-out of this instantiation also rebuilds the
   // final tile in LDS and sums its columns there (the no-residual case sums the accumulators in the default kernels)
   if (a.gn_part && (a.res1 || a.res2)) return bn == 256 ? launch_pp<256, 256, 2048>(a, s) : launch_pp<256, 320, 2048>(a, s);
+  if (a.a2) return bn == 256 ? launch_pp<256, 256, 4096>(a, s) : launch_pp<256, 320, 4096>(a, s);   // (host: never with the above)
 #ifdef SP_GEMM_EXPERIMENTS
   if (bm == 256 && bn == 256) switch (a.dbg) {
     case 1: return launch_pp<256, 256, 1>(a, s);

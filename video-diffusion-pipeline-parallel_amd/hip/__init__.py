@@ -39,6 +39,7 @@ class GemmDesc(ctypes.Structure):
         ("ln_out", ctypes.c_void_p), ("ln_out_eps", ctypes.c_float),
         ("w_group_rows", ctypes.c_int64), ("w_group_stride", ctypes.c_int64),
         ("gn_part", ctypes.c_void_p),
+        ("a2", ctypes.c_void_p), ("lda2", ctypes.c_int64), ("cin2", ctypes.c_int),
     ]
 
 

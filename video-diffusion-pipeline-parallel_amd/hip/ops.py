@@ -82,7 +82,8 @@ def _rows(t: torch.Tensor, name: str, ld: int) -> torch.Tensor:
 def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=None, bias=None,
          bias2=None, bias2_rows=0, ldb2=0, res1=None, r1scale=1.0, res2=None, r2scale=1.0, oscale=1.0,
          geglu=False, n_store=0, ldd=None, ldr1=None, ldr2=None, ln_stats=None, ln_colsum=None, euler=None,
-         workspace=None, ln_out=None, ln_out_eps=1e-5, w_group_rows=0, w_group_stride=0, gn_part=None):
+         workspace=None, ln_out=None, ln_out_eps=1e-5, w_group_rows=0, w_group_stride=0, gn_part=None, a2=None, cin2=0,
+         lda2=None):
     """``out[m][:] = epilogue(sum_taps A_tap @ W^T)``; see ``sp_gemm_desc`` in include/svdpipe.h.
     ``ln_stats`` / ``ln_colsum``: LayerNorm folded into the contraction (``a`` is the UN-normalised tensor).
     ``w_group_rows`` / ``w_group_stride``: ``w`` holds one weight matrix per group of that many output rows (a GroupNorm
@@ -118,6 +119,9 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
             raise ValueError("ln_out must be a contiguous float32 [m][2] tensor")
         d.ln_out, d.ln_out_eps = ln_out.data_ptr(), float(ln_out_eps)
     d.w_group_rows, d.w_group_stride = int(w_group_rows), int(w_group_stride)
+    if a2 is not None:                 # extra linear tap: rows of a second tensor against the weight's last cin2 columns
+        _f16(a2, "a2")
+        d.a2, d.lda2, d.cin2 = a2.data_ptr(), int(lda2 if lda2 is not None else a2.stride(0)), int(cin2)
     if gn_part is not None:            # fp32 [m/256][2][n][2]: per-tile column sums for the next GroupNorm (svdpipe.h)
         if gn_part.dtype != torch.float32 or not gn_part.is_cuda or gn_part.numel() < (m // 256) * 2 * n * 2:
             raise TypeError("gn_part must be a float32 HIP tensor of (m/256)*2*n*2 elements")
@@ -125,8 +129,9 @@ def gemm(a, w, out, *, m, n, cin, mode=A_LINEAR, lda=None, conv=None, temporal=N
     taps = 9 if mode == A_CONV3X3 else 3 if mode == A_TEMPORAL3 else 1
     # algorithmic bytes of this launch: every operand element once (A without tap re-reads), output and residuals once
     a_rows = d.n_img * d.hin * d.win if mode == A_CONV3X3 else m
-    nbytes = 2.0 * (a_rows * cin + n * taps * cin + m * (n_store or nout) * (1 + (res1 is not None) + (res2 is not None)))
-    with _Timed("gemm", 2.0 * m * n * taps * cin, nbytes, (m, n, cin, mode, bool(geglu))) as tm:
+    k2 = int(cin2) if a2 is not None else 0          # (the extra linear tap's channels count like any other K)
+    nbytes = 2.0 * (a_rows * cin + m * k2 + n * (taps * cin + k2) + m * (n_store or nout) * (1 + (res1 is not None) + (res2 is not None)))
+    with _Timed("gemm", 2.0 * m * n * (taps * cin + k2), nbytes, (m, n, cin, mode, bool(geglu))) as tm:
         _check(load().sp_gemm_f16(ctypes.byref(d), _stream()), "sp_gemm_f16")
         if PROFILE is not None:      # which kernel template took it (per-template FLOPs in the profile summary)
             tm.tag = tm.tag + (load().sp_gemm_last_kernel().decode(),)

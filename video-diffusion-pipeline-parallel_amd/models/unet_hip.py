@@ -160,6 +160,9 @@ class SVDUNetHIP:
         # ... also for outputs that residuals are added to (the final tile is rebuilt in LDS and summed there); 0: only
         # the no-residual producers (sums straight from the accumulators)
         self.gn_epilogue_residual = os.environ.get("VDPP_GN_EPILOGUE_RES", "1") != "0"
+        # a resnet's 1x1 shortcut convolution as an extra linear tap of its second 3x3 convolution (levels with more rows
+        # than the split-K / small-tile routes take: the fused contraction runs on the 256-row ping-pong tiles)
+        self.fold_shortcut = os.environ.get("VDPP_FOLD_SHORTCUT", "1") != "0"
         self.device = dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("SVDUNetHIP runs on an MI355X HIP device only (no CPU fallback)")
@@ -250,10 +253,26 @@ class SVDUNetHIP:
             te_s=self._reg_temb(sd, s + ".time_emb_proj"),
             n2=_Norm(sd, s + ".norm2", dev, eps), c2=_Dense.conv3x3(sd, s + ".conv2", dev),
             sc=_Dense.linear(sd, s + ".conv_shortcut", dev) if cin != cout else None,
+            c2sc=self._conv_plus_shortcut(sd, s, dev) if cin != cout else None,
             tn1=_Norm(sd, t + ".norm1", dev, eps), tc1=_Dense.tconv(sd, t + ".conv1", dev),
             te_t=self._reg_temb(sd, t + ".time_emb_proj"),
             tn2=_Norm(sd, t + ".norm2", dev, eps), tc2=_Dense.tconv(sd, t + ".conv2", dev),
         )
+
+    @staticmethod
+    def _conv_plus_shortcut(sd, s, dev):
+        """conv2(h) + conv_shortcut(x) as ONE contraction: weight [N][9*C | Cin] (the shortcut's columns behind the nine
+        taps), bias b2 + b_sc.  None where the widths do not fit the extra-tap kernel (Cin a multiple of 64, no padding)."""
+        w2, wsc = sd[s + ".conv2.weight"], sd[s + ".conv_shortcut.weight"]
+        cout, c = w2.shape[:2]
+        cin = wsc.shape[1]
+        if cout % 64 or c % 64 or cin % 64 or not (cout % 256 == 0 or cout % 320 == 0):
+            return None
+        w = torch.cat([W.pack_conv3x3(w2.to(dev), c, cout), W.pack_linear(wsc).to(dev)], dim=1).contiguous()
+        b = (sd[s + ".conv2.bias"].float() + sd[s + ".conv_shortcut.bias"].float()).to(dev).contiguous()
+        layer = _Dense(w, b, cin=c, mode=ops.A_CONV3X3, n_true=cout)
+        layer.cin2 = cin
+        return layer
 
     def _attn(self, sd, p, dev, norm):
         """``norm``: state_dict prefix of the LayerNorm in front of the Q/K/V projections (folded into them)."""
@@ -482,8 +501,14 @@ class SVDUNetHIP:
         n1 = p["c1"].n
         t = self._gemm(r, p["c1"], t, conv=geom, bias2=r.temb[p["te_s"]:p["te_s"] + n1], bias2_rows=r.m, gn_next=True)
         t = self._gn(r, p["n2"], t, temporal=False, silu=True)
-        skip = x if p["sc"] is None else self._gemm(r, p["sc"], x)
-        s = self._gemm(r, p["c2"], t, conv=geom, res1=skip, r1scale=1.0, gn_next=True)
+        if p["sc"] is not None and p["c2sc"] is not None and self.fold_shortcut and r.m > self.SPLITK_MAX_ROWS \
+                and r.m % 256 == 0:
+            # the shortcut convolution rides in conv2's K loop (sp_gemm_desc.a2): no skip tensor, and no residual in front of
+            # the temporal block's first norm (its column sums then come straight from the accumulators)
+            s = self._gemm(r, p["c2sc"], t, conv=geom, a2=x, cin2=p["c2sc"].cin2, lda2=x.stride(0), gn_next=True)
+        else:
+            skip = x if p["sc"] is None else self._gemm(r, p["sc"], x)
+            s = self._gemm(r, p["c2"], t, conv=geom, res1=skip, r1scale=1.0, gn_next=True)
         # temporal branch + AlphaBlender: alpha*s + (1-alpha)*(s + conv2(...)) = s + (1-alpha)*conv2(...)
         t = self._gn(r, p["tn1"], s, temporal=True, silu=True)
         t = self._gemm(r, p["tc1"], t, bias2=r.temb[p["te_t"]:p["te_t"] + p["cout"]], bias2_rows=r.m, gn_next=True)
