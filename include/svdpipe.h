@@ -101,8 +101,9 @@ typedef struct sp_gemm_desc {
   void *workspace; size_t workspace_bytes;
   /* LayerNorm statistics of the OUTPUT rows, for the next contraction's ln_stats (what a following sp_ln_stats_f16 pass
      over d would compute, without that pass): ln_out = fp32 [m][2] (mean, rstd = 1/sqrt(var + ln_out_eps)) of the n
-     stored fp16 values of every row.  A row must be one tile (n = 256 or 320) or two (n = 512 or 640: the per-tile sums
-     then pass through `workspace`, >= m * 16 bytes, 8-byte aligned, and a second small kernel folds them); no geglu, no
+     stored fp16 values of every row.  A row must be one to four 256- or 320-column tiles (n = 256 ... 1280; with more
+     than one tile the per-tile sums pass through `workspace`, >= m * tiles * 8 bytes, 8-byte aligned, and a second small
+     kernel folds them); no geglu, no
      n_store, no Euler tail; the call runs on the ping-pong kernels (no split-K).  Sums are folded in a fixed order:
      bit-reproducible.  NULL = off. */
   float *ln_out; float ln_out_eps;

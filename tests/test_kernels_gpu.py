@@ -565,7 +565,9 @@ def test_gemm_rejects_row_groups_that_tiles_would_straddle():
 @pytest.mark.parametrize("m,cin,n,extras,offset", [(1000, 320, 320, "", 0.0), (129024, 320, 320, "r", 2.0), (2016, 1280, 320, "r2", 0.0),
                                                     (5000, 640, 256, "b2", 20.0), (777, 64, 320, "r", 20.0), (64512, 1280, 256, "", 0.0),
                                                     # rows of two tiles: per-tile sums through a workspace + finalize kernel
-                                                    (64512, 640, 640, "r", 0.0), (3001, 2560, 640, "r2", 20.0), (1000, 320, 512, "b2", 2.0)])
+                                                    (64512, 640, 640, "r", 0.0), (3001, 2560, 640, "r2", 20.0), (1000, 320, 512, "b2", 2.0),
+                                                    # ... of three and four tiles (the 576-token level's 1,280 channels)
+                                                    (16128, 1280, 1280, "r", 0.0), (2500, 256, 1024, "r2", 2.0), (900, 128, 960, "", 20.0)])
 def test_gemm_output_row_layernorm_statistics(m, cin, n, extras, offset):
     """sp_gemm_desc.ln_out: the epilogue leaves (mean, rstd) of every stored output row beside the output, what an
     sp_ln_stats_f16 pass over d would compute (so that the next contraction's folded LayerNorm needs no pass of its
@@ -590,8 +592,9 @@ def test_gemm_output_row_layernorm_statistics(m, cin, n, extras, offset):
     ops.gemm(ad, wd, plain, **kw)
     out = torch.empty(m, n, dtype=torch.float16, device=DEV)
     st = torch.full((m + 1, 2), 7.0, dtype=torch.float32, device=DEV)
-    if n > 320:
-        kw["workspace"] = torch.empty(m, 4, dtype=torch.float32, device=DEV)
+    tiles = n // (320 if n % 320 == 0 else 256)
+    if tiles > 1:
+        kw["workspace"] = torch.empty(m, 2 * tiles, dtype=torch.float32, device=DEV)
     ops.gemm(ad, wd, out, ln_out=st[:m], ln_out_eps=1e-5, **kw)
     assert "gemm_pp_kernel" in ops.load().sp_gemm_last_kernel().decode()
     assert torch.all(st[m] == 7.0)
@@ -608,9 +611,9 @@ def test_gemm_output_row_layernorm_statistics(m, cin, n, extras, offset):
     out_b = torch.empty_like(out); st_b = torch.empty(m, 2, dtype=torch.float32, device=DEV)
     ops.gemm(ad, wd, out_b, ln_out=st_b, ln_out_eps=1e-5, **kw)
     assert torch.equal(out_b, out) and torch.equal(st_b, st[:m])
-    with pytest.raises(ops.HipKernelError, match="ln_out"):           # a row must fit one tile
-        ops.gemm(ad, h(torch.randn(960, cin, generator=g)).half().to(DEV), torch.empty(m, 960, dtype=torch.float16, device=DEV),
-                 m=m, n=960, cin=cin, ln_out=st_b, ln_out_eps=1e-5)
+    with pytest.raises(ops.HipKernelError, match="ln_out"):           # at most four tiles per row
+        ops.gemm(ad, h(torch.randn(1920, cin, generator=g)).half().to(DEV), torch.empty(m, 1920, dtype=torch.float16, device=DEV),
+                 m=m, n=1920, cin=cin, ln_out=st_b, ln_out_eps=1e-5, workspace=torch.empty(m, 12, dtype=torch.float32, device=DEV))
 
 
 @pytest.mark.parametrize("m,c,n,geglu,route", [(1000, 320, 960, False, 0), (5000, 640, 1920, False, 2), (40000, 320, 2560, True, 3),

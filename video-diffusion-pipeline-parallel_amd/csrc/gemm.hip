@@ -517,7 +517,7 @@ int dispatch(GemmArgs &a, const sp_gemm_desc *d, hipStream_t s) {
   if (a.gn_part || a.a2)                       // per-tile column sums / the extra linear tap live in the 256-row ping-pong tiles
     return launch_pp(a, 256, ok320 ? 320 : 256, s);
   if (a.ln_out) {
-    const int bn = d->n <= 320 ? d->n : d->n / 2;
+    const int bn = d->n % 320 == 0 ? 320 : 256;
     int bm = makespan(d->m, d->n, 192, bn) * 1.06 < makespan(d->m, d->n, 256, bn) ? 192 : 256;
     if (!group_ok(bm)) bm = group_ok(256) ? 256 : 192;
     SP_REQUIRE(group_ok(bm), "sp_gemm_f16: w_group_rows=%lld fits neither 256- nor 192-row tiles", (long long)a.w_group_rows);
@@ -655,8 +655,9 @@ extern "C" size_t sp_gemm_workspace_bytes(const sp_gemm_desc *d) {
   const int forced = splitk_slices(d, taps, true);
   if (forced > sk) sk = forced;                             // (enough for a forced split in tests as well)
   size_t need = (size_t)sk * d->m * d->n * sizeof(float);
-  // ln_out over rows of two tiles (n = 512 / 640): the per-tile (sum, sum of squares) pairs meet here
-  const size_t ln_part = (d->ln_out && d->n > 320) ? (size_t)d->m * 2 * 2 * sizeof(float) : 0;
+  // ln_out over rows of several tiles (n = 512 ... 1280): the per-tile (sum, sum of squares) pairs meet here
+  const int ltiles = d->n % 320 == 0 ? d->n / 320 : d->n / 256;
+  const size_t ln_part = (d->ln_out && ltiles > 1) ? (size_t)d->m * ltiles * 2 * sizeof(float) : 0;
   return need > ln_part ? need : ln_part;
 }
 
@@ -727,13 +728,15 @@ extern "C" int sp_gemm_f16(const sp_gemm_desc *d, void *stream) {
     a.w_group_rows = d->w_group_rows; a.w_group_stride = d->w_group_stride;
   }
   if (d->ln_out) {
-    SP_REQUIRE((d->n == 256 || d->n == 320 || d->n == 512 || d->n == 640) && !d->geglu && d->n_store == 0 && !d->euler_out &&
+    const int lbn = d->n % 320 == 0 ? 320 : 256, ltiles = d->n / lbn;       // column tiles per row
+    SP_REQUIRE(d->n % lbn == 0 && ltiles >= 1 && ltiles <= 4 && !d->geglu && d->n_store == 0 && !d->euler_out &&
                    d->ln_out_eps > 0.f,
-               "sp_gemm_f16: ln_out needs rows of one or two tiles (n = 256, 320, 512 or 640, got %d), no geglu / n_store / "
-               "Euler tail", d->n);
-    if (d->n > 320) {                          // two tiles per row: per-tile sums go through the caller's workspace
-      SP_REQUIRE(d->workspace && ((uintptr_t)d->workspace & 7) == 0 && d->workspace_bytes >= (size_t)d->m * 2 * 2 * sizeof(float),
-                 "sp_gemm_f16: ln_out with n = %d needs a workspace of m * 16 bytes (8-byte aligned)", d->n);
+               "sp_gemm_f16: ln_out needs rows of one to four 256- or 320-column tiles (n = 256 ... 1280, got %d), no geglu / "
+               "n_store / Euler tail", d->n);
+    if (ltiles > 1) {                          // several tiles per row: per-tile sums go through the caller's workspace
+      SP_REQUIRE(d->workspace && ((uintptr_t)d->workspace & 7) == 0 &&
+                     d->workspace_bytes >= (size_t)d->m * ltiles * 2 * sizeof(float),
+                 "sp_gemm_f16: ln_out with n = %d needs a workspace of m * %d bytes (8-byte aligned)", d->n, ltiles * 8);
       a.ln_part = (float *)d->workspace;
     }
   }

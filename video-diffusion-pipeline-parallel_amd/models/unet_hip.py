@@ -163,6 +163,9 @@ class SVDUNetHIP:
         # a resnet's 1x1 shortcut convolution as an extra linear tap of its second 3x3 convolution (levels with more rows
         # than the split-K / small-tile routes take: the fused contraction runs on the 256-row ping-pong tiles)
         self.fold_shortcut = os.environ.get("VDPP_FOLD_SHORTCUT", "1") != "0"
+        # LayerNorm row statistics from the producing contraction's epilogue also for rows of three / four column tiles
+        # (1,280 channels at the 576-token level)
+        self.ln_out_wide = os.environ.get("VDPP_LN_OUT_WIDE", "1") != "0"
         self.device = dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("SVDUNetHIP runs on an MI355X HIP device only (no CPU fallback)")
@@ -404,10 +407,11 @@ class SVDUNetHIP:
             gn_part = torch.empty((m // 256, 2, layer.n, 2), dtype=torch.float32, device=self.device)
             kw.update(gn_part=gn_part)
         st_buf = kw.pop("ln_out_buf", None)             # caller-provided rows of a larger statistics tensor (_ff_pair chunks)
-        if ln_next is not None and self._ln_out_ok(layer) and "euler" not in kw:
+        if ln_next is not None and self._ln_out_ok(layer, m) and "euler" not in kw:
             st = st_buf if st_buf is not None else torch.empty((m, 2), dtype=torch.float32, device=self.device)
             kw.update(ln_out=st, ln_out_eps=ln_next.ln_eps)
-            ws = torch.empty((m, 4), dtype=torch.float32, device=self.device) if layer.n_true > 320 else None
+            tiles = layer.n_true // (320 if layer.n_true % 320 == 0 else 256)
+            ws = torch.empty((m, 2 * tiles), dtype=torch.float32, device=self.device) if tiles > 1 else None
         if out is None:
             out = self._buf(m, layer.n_true)
         elif out.shape != (m, layer.n_true):
@@ -432,10 +436,14 @@ class SVDUNetHIP:
             out._row_ln_stats = (st, ln_next.ln_eps, out.data_ptr(), _version(out), tuple(out.shape))
         return out
 
-    @staticmethod
-    def _ln_out_ok(layer: _Dense) -> bool:
-        """Can this contraction's epilogue leave the next LayerNorm's row statistics (a row = one or two tiles)?"""
-        return layer.n_true in (256, 320, 512, 640) and layer.n == layer.n_true and not layer.geglu
+    def _ln_out_ok(self, layer: _Dense, m: int) -> bool:
+        """Can this contraction's epilogue leave the next LayerNorm's row statistics?  A row = one or two column tiles at
+        any row count; three or four (1,024 / 1,280 channels: the 576-token level) only where the large ping-pong tiles
+        are what the contraction runs on anyway (more rows than the small-tile / split-K routes take)."""
+        if layer.n != layer.n_true or layer.geglu:
+            return False
+        return layer.n_true in (256, 320, 512, 640) or (self.ln_out_wide and layer.n_true in (768, 960, 1024, 1280)
+                                                        and m > self.SPLITK_MAX_ROWS)
 
     def _ln_stats(self, layer: _Dense, x, **kw):
         """(mean, rstd) per row of x for the LayerNorm folded into ``layer``."""
@@ -602,7 +610,7 @@ class SVDUNetHIP:
             out = self._buf(m, ff2.n_true)
         ln_next = epi.pop("ln_next", None)
         st_next = None
-        if ln_next is not None and self._ln_out_ok(ff2):
+        if ln_next is not None and self._ln_out_ok(ff2, m):
             st_next = torch.empty((m, 2), dtype=torch.float32, device=self.device)
         for r0 in range(0, m, rows):
             r1 = min(m, r0 + rows)
