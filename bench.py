@@ -923,7 +923,11 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world == args.gpus and world > 1 and os.environ.get("VDPP_BENCH_WORKER") != "1" and not args.no_fallback:
+    # Supervised ranks need a launcher whose ranks share one parent process on one node (torchrun: TORCHELASTIC_RUN_ID is
+    # set by its agent; this script's own launcher goes through torchrun too) or an explicit job name for the rendezvous
+    # directory (VDPP_BENCH_JOB); under anything else the rank runs in the launched process itself, as before round 5.
+    supervisable = any(os.environ.get(k) for k in ("TORCHELASTIC_RUN_ID", "VDPP_BENCH_JOB"))
+    if world == args.gpus and world > 1 and os.environ.get("VDPP_BENCH_WORKER") != "1" and not args.no_fallback and supervisable:
         sys.exit(supervise_rank(args, sys.argv[1:]))        # standard library only up to here: the supervisor never touches the GPU
     if world != args.gpus:
         # never report one job size under the name of another
