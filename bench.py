@@ -1206,12 +1206,14 @@ def main():
 
     # ---- per-kernel roofline of the dominant kernel, measured live with events on the launch stream
     if rehearse:
+        if n > 1:
+            dog.beat("final barrier")
+            dist.barrier()      # the line is printed only once every rank has come this far: a failed attempt prints nothing
         if rank == 0:
             out["rehearsal"] = "cpu"
             out.pop("step_roofline", None)
             print(json.dumps(out), flush=True)
         if n > 1:
-            dist.barrier()
             finalize_distributed()
         dog.stop()
         return
@@ -1330,11 +1332,14 @@ def main():
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(args.frames, args.height, args.width, T)
         out["cpu_simulator"] = cpu_simulator()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if n > 1:
         dog.beat("final barrier (rank 0 measures the per-kernel roofline alone before it)")
         dist.barrier()          # rank 0 ran the roofline leg alone; leave together
+    if rank == 0:
+        # (behind the barrier: an attempt in which some rank never got here prints no line, so that the supervisors' next
+        # attempt cannot put a second one on stdout)
+        print(json.dumps(out), flush=True)
+    if n > 1:
         finalize_distributed()
     dog.stop()
 
