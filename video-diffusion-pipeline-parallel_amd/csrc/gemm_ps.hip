@@ -86,10 +86,21 @@ __device__ __forceinline__ void swap16(unsigned &a, unsigned &b) {
   b = r[1];
 }
 
+// LDS-DMA piece with the address as (wave-uniform 64-bit base, 32-bit lane offset): the saddr form, written out because hipcc
+// otherwise keeps the lane offsets zero-extended in register pairs and adds the base per piece (whole-line pairs issue from
+// four bases: 8-16 registers the 256 x 256 tiles do not have).  M0 = LDS byte address of the piece.
+__device__ __forceinline__ void glds16_s(const char *sbase, unsigned voff, char *lds_dst) {
+  const unsigned l = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds_dst;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(voff), "s"(sbase), "s"(l) : "memory", "m0");
+}
+
 template <int BM, int BN, int WM, int WN, bool GEGLU, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
   static_assert(WM * WN == 8, "eight waves");
   constexpr bool PAIR = (VAR & 1) != 0;                    // K-steps staged in pairs (see stage2)
+  constexpr bool FULL = (VAR & 2) != 0;                    // ... as ONE 64-deep image of whole 128-byte lines (see stage2)
+  static_assert(!FULL || PAIR, "whole-line pieces cover two K-steps");
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
   constexpr int TNO = GEGLU ? TN / 2 : TN;                 // output sub-tiles (16 columns) per wave
   static_assert(TNO % 2 == 0, "output sub-tiles are written in pairs");
@@ -143,19 +154,32 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
   // handful of scalar instructions.  Rows past M read row M-1 instead (their outputs are never stored).
   const int lrow = lane >> 2, lchunk = lane & 3;  // 16 rows x 4 chunks per 1-KiB piece
   const int nk = p.k >> 5;                        // K-steps per tile (host: nk >= 8)
+  // FULL: a piece is 8 rows x 128 B (lane l: row l >> 3, LDS chunk l & 7 holding the line's chunk (l & 7) ^ (row & 7)); piece
+  // i*8 + wave covers rows (i*8 + wave)*8.. of the tile's first half, its partner the same rows of the second half
+  const int frow = lane >> 3, fchunk = ((lane & 7) ^ (lane >> 3)) * 8;
   unsigned a_off[A_LOADS], b_off[B_LOADS];
 #pragma unroll
   for (int j = 0; j < B_LOADS; ++j) {
-    const int r = (j * 8 + wave) * 16 + lrow;
-    b_off[j] = (unsigned)(((r < BN ? r : 0) * p.k + (lchunk ^ swz4(r)) * 8) * 2);
+    if constexpr (FULL) {
+      const int r = (j * 8 + wave) * 8 + frow;
+      b_off[j] = (unsigned)(((r < BN / 2 ? r : 0) * p.k + fchunk) * 2);
+    } else {
+      const int r = (j * 8 + wave) * 16 + lrow;
+      b_off[j] = (unsigned)(((r < BN ? r : 0) * p.k + (lchunk ^ swz4(r)) * 8) * 2);
+    }
   }
   const char *a_base, *b_base;
   auto set_tile = [&](int tm, int tn) {
     const int rows_left = p.m - tm * BM;          // >= 1
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-      const int r = (i * 8 + wave) * 16 + lrow;
-      a_off[i] = (unsigned)((min(r < BM ? r : 0, rows_left - 1) * (int)p.lda + (lchunk ^ swz4(r)) * 8) * 2);
+      if constexpr (FULL) {
+        const int r = (i * 8 + wave) * 8 + frow;
+        a_off[i] = (unsigned)(((r < BM / 2 ? r : 0) * (int)p.lda + fchunk) * 2);   // (host: m % BM == 0, no row to clamp)
+      } else {
+        const int r = (i * 8 + wave) * 16 + lrow;
+        a_off[i] = (unsigned)((min(r < BM ? r : 0, rows_left - 1) * (int)p.lda + (lchunk ^ swz4(r)) * 8) * 2);
+      }
     }
     a_base = (const char *)p.a + (int64_t)tm * BM * p.lda * 2;
     b_base = (const char *)p.w + (int64_t)tn * BN * p.k * 2;
@@ -181,22 +205,42 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
   // with the other half requested one K-step (32 KiB of other lines through a 32 KiB L1) later every line travels from
   // L2 twice.  Back to back the second half hits in L1: tools/dma_probe.hip, all CUs on L2-resident rows, 63 -> 104 GB/s
   // per CU.  The kernel is not bound there (+0-4 %), see DESIGN.md.  (nk is even: the host checks.)
+  // FULL (round 5): the pair of slots holds ONE image of 64-deep rows, [A: BM x 128 B | B: BN x 128 B], and a piece is 8 whole
+  // lines instead of 16 half lines -- half the line requests per KiB on the texture path (tools/experiments/gemm_w2_probe.hip:
+  // -5..7 % on a K loop against the same loop fed with half-line pieces).  Same number of pieces per wave and pair.
   auto stage2 = [&]() {
     char *sa = smem + p_slot * STAGE;              // p_slot is 0 or 2
-    char *sb = sa + A_BYTES;
     p_slot ^= 2;
+    if constexpr (FULL) {
+      char *sb = sa + 2 * A_BYTES;
+      const char *b_hi = b_base + (int64_t)(BN / 2) * p.k * 2, *a_hi = a_base + (int64_t)(BM / 2) * p.lda * 2;
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i)
-      if (i < A_LOADS_HI || wave < A_SPLIT) {
-        glds16(a_base + a_off[i], sa + (i * 8 + wave) * 1024);
-        glds16(a_base + a_off[i] + SBK * 2, sa + STAGE + (i * 8 + wave) * 1024);
-      }
+      for (int i = 0; i < A_LOADS; ++i)
+        if (i < A_LOADS_HI || wave < A_SPLIT) {
+          glds16_s(a_base, a_off[i], sa + (i * 8 + wave) * 1024);
+          glds16_s(a_hi, a_off[i], sa + A_BYTES + (i * 8 + wave) * 1024);
+        }
 #pragma unroll
-    for (int j = 0; j < B_LOADS; ++j)
-      if (j < B_LOADS_HI || wave < B_SPLIT) {
-        glds16(b_base + b_off[j], sb + (j * 8 + wave) * 1024);
-        glds16(b_base + b_off[j] + SBK * 2, sb + STAGE + (j * 8 + wave) * 1024);
-      }
+      for (int j = 0; j < B_LOADS; ++j)
+        if (j < B_LOADS_HI || wave < B_SPLIT) {
+          glds16_s(b_base, b_off[j], sb + (j * 8 + wave) * 1024);
+          glds16_s(b_hi, b_off[j], sb + B_BYTES + (j * 8 + wave) * 1024);
+        }
+    } else {
+      char *sb = sa + A_BYTES;
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i)
+        if (i < A_LOADS_HI || wave < A_SPLIT) {
+          glds16(a_base + a_off[i], sa + (i * 8 + wave) * 1024);
+          glds16(a_base + a_off[i] + SBK * 2, sa + STAGE + (i * 8 + wave) * 1024);
+        }
+#pragma unroll
+      for (int j = 0; j < B_LOADS; ++j)
+        if (j < B_LOADS_HI || wave < B_SPLIT) {
+          glds16(b_base + b_off[j], sb + (j * 8 + wave) * 1024);
+          glds16(b_base + b_off[j] + SBK * 2, sb + STAGE + (j * 8 + wave) * 1024);
+        }
+    }
     a_base += SBK * 4;
     b_base += SBK * 4;
   };
@@ -211,12 +255,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
     for (int s = 0; s < SSTAGES; ++s) stage();     // the whole ring: K-steps 0..3 (nk >= 8)
   }
 
-  const int rd_chunk = (fq ^ swz4(fr)) << 4;       // fragment rows are (multiple of 16) + fr
-  int offw[TN], offa[TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i) offw[i] = A_BYTES + (wn * WTN + i * 16 + fr) * 64 + rd_chunk;
-#pragma unroll
-  for (int j = 0; j < TM; ++j) offa[j] = (wm * WTM + j * 16 + fr) * 64 + rd_chunk;
+  // fragment rows are (multiple of 16) + fr.  FULL: K-step ks of the pair reads chunk (4 * ks + fq) ^ (row & 7) of its
+  // 128-byte row: the offsets below are those of the even K-step, the odd one's are the same ^ 64
+  const int rd_chunk = FULL ? (fq ^ (fr & 7)) << 4 : (fq ^ swz4(fr)) << 4;
+  constexpr int ROWB = FULL ? 128 : 64;
+  // one address per operand and lane; the sub-tiles are 16 rows (immediate offsets) apart, and ^ 64 commutes with them
+  const int offw0 = (FULL ? 2 * A_BYTES : A_BYTES) + (wn * WTN + fr) * ROWB + rd_chunk;
+  const int offa0 = (wm * WTM + fr) * ROWB + rd_chunk;
 
   // output addressing of this lane: even 16-lane rows own 8 channels of the first sub-tile of a pair, odd rows of the second
   const int ocol = (fq & 1) * 16 + (fq >> 1) * 8;  // column of the 16-byte piece inside a pair of sub-tiles (32 columns)
@@ -250,13 +295,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ps_kernel(const GemmArgs p) {
 #ifdef SP_GEMM_EXPERIMENTS
     PS_STEP(ps_kidx); ++ps_kidx;
 #endif
-    const char *sa = smem + read_slot * STAGE;
+    const char *sa = smem + (FULL ? read_slot & ~1 : read_slot) * STAGE;
+    const int odd = FULL ? (read_slot & 1) << 6 : 0;
     read_slot = read_slot + 1 == SSTAGES ? 0 : read_slot + 1;
     f16x8 fw[TN], fa[TM];
 #pragma unroll
-    for (int i = 0; i < TN; ++i) fw[i] = *(const f16x8 *)(sa + offw[i]);
+    for (int i = 0; i < TN; ++i) fw[i] = *(const f16x8 *)(sa + (FULL ? offw0 ^ odd : offw0) + i * 16 * ROWB);
 #pragma unroll
-    for (int j = 0; j < TM; ++j) fa[j] = *(const f16x8 *)(sa + offa[j]);
+    for (int j = 0; j < TM; ++j) fa[j] = *(const f16x8 *)(sa + (FULL ? offa0 ^ odd : offa0) + j * 16 * ROWB);
     __builtin_amdgcn_sched_barrier(0);
     if (first) {
       // this tile's bias vectors (its epilogue is >= 8 K-steps away; the previous tile's epilogue has read its own)
@@ -536,9 +582,14 @@ int launch_ps(GemmArgs &a, int bm, int bn, hipStream_t s) {
   // K >= 640: K-steps staged in pairs (+3-4 % on the FF contractions of the 32,256- and 8,064-row levels; at K = 320 a
   // tile is 10 K-steps and the shorter prefetch distance of the pairs costs 4 %)
   bool pair = a.k >= 20 * SBK && (a.k / SBK) % 2 == 0;
+  // pairs as one image of whole 128-byte lines (VAR 3): the activation rows must start on a line (lda % 64, base % 128)
+  // and every tile be whole (the second half's rows are addressed from the first half's, without the clamp at row m-1)
+  bool full = pair && a.m % bm == 0 && a.lda % 64 == 0 && a.k % 64 == 0 && ((uintptr_t)a.a & 127) == 0 && ((uintptr_t)a.w & 127) == 0;
 #ifdef SP_GEMM_EXPERIMENTS
   if (a.dbg & 16) pair = false;
+  if (a.dbg & 128) full = false;
 #endif
+  if (pair && full) return launch_ps_v<3>(a, bm, bn, s);
   return pair ? launch_ps_v<1>(a, bm, bn, s) : launch_ps_v<0>(a, bm, bn, s);
 }
 
