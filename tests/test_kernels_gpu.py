@@ -116,6 +116,8 @@ def test_gemm_large_tile_geglu_conv_temporal(force_large_tiles):
 
 
 @pytest.mark.parametrize("bm,m,n,k,geglu", [(256, 32256, 2560, 320, True), (192, 32256, 2560, 320, True),
+                                            # K >= 640, whole tiles, rows on 128-byte lines: K-step pairs as ONE whole-line image (VAR 3)
+                                            (256, 32256, 2560, 640, True), (256, 32256, 1024, 640, False), (192, 16128, 2560, 1280, True),
                                             (256, 40000, 1280, 320, False), (192, 129024 // 2, 256, 640, False),
                                             (192, 50001, 960, 320, False), (192, 36000, 320, 1280, False),
                                             # 128 x 320 tiles (4 x 2 waves): every N = 320 k of the two outer levels
@@ -151,8 +153,13 @@ def test_gemm_persistent_stream_many_tiles(bm, m, n, k, geglu):
         wdev = w.half().to(DEV)
     with (ops.gemm_route(3, bm=256, bn=192) if bm == -192 else ops.gemm_route(3, bm=bm)):
         ops.gemm(a.half().to(DEV), wdev, out[1:m + 1], **kw)
+        name = ops.load().sp_gemm_last_kernel().decode()
         if bm == -192:
-            assert ops.load().sp_gemm_last_kernel().decode().startswith("gemm_ps_kernel<256, 192"), ops.load().sp_gemm_last_kernel()
+            assert name.startswith("gemm_ps_kernel<256, 192"), name
+        if k >= 640 and name.startswith("gemm_ps_kernel<"):   # whole-line pairs exactly where launch_ps says, half-line pairs otherwise
+            assert name.endswith(", 3>" if m % int(name.split("<")[1].split(",")[0]) == 0 else ", 1>"), name
+        if (bm, k) == (256, 640):
+            assert name.startswith("gemm_ps_kernel<256, 256") and name.endswith(", 3>"), name
     torch.cuda.synchronize()
     assert torch.all(out[0] == 7.0) and torch.all(out[m + 1] == 7.0), "guard rows written"
     check(out[1:m + 1], y)
