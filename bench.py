@@ -1086,18 +1086,36 @@ def main():
         if cuda:
             torch.cuda.reset_peak_memory_stats(device)      # ref src/modes/benchmark.py:240-249: peak of the timed region
         done_events = []
+        # shader clock over the timed region (rank 0, real model): a ~2 us stamp of the shader-clock and 100 MHz counters at the
+        # start and behind every finished sample, in stream order (sp_clock_stamp) -- `roofline.clock_ghz_live`
+        stamps = None
+        if cuda and not rehearse and rank == 0:
+            try:
+                stamps = ops.ClockStamps(device, n_samples + 2)
+            except Exception as exc:  # noqa: BLE001
+                print(f"bench.py: no clock stamps ({exc!r})", file=sys.stderr, flush=True)
 
         def on_done(_idx):   # runs on the finishing sample's stream, right after its last step was enqueued
             ev = new_event(enable_timing=True); ev.record(); done_events.append(ev)
+            if stamps is not None:
+                stamps.stamp()
 
         stage.sample_done_hook = on_done
         t0 = time.perf_counter()
         start_ev = new_event(enable_timing=True); start_ev.record()
+        if stamps is not None:
+            stamps.stamp()
         stage.run_many(n_samples, input_supplier=(lambda i: supplier(warm_samples + i)) if (rank == 0 or ring) else None)
         stage.drain()
         dog.beat("fence after the timed region")
         fence()
         elapsed = time.perf_counter() - t0
+        clock_live = None
+        if stamps is not None:
+            try:
+                clock_live = stamps.ghz()        # (GHz, seconds between the first and the last stamp, XCDs paired)
+            except Exception as exc:  # noqa: BLE001
+                print(f"bench.py: clock stamps unreadable ({exc!r})", file=sys.stderr, flush=True)
     frames_out = None
     if not rehearse and not args.no_decode and (args.emit_frames or n == 1):
         dog.beat("frames-out leg")
@@ -1203,6 +1221,10 @@ def main():
                                 "frac": flops_exec / 1e12 / (ms_forward / 1e3) / PEAK_FP16_TFLOPS,
                                 "note": "executed FLOPs of one UNet forward / time per forward"
                                         + ("" if n == 1 else " on the bottleneck stage (includes pipeline fill of the timed region)")}
+        if clock_live and clock_live[0]:
+            # the same fraction against the peak at the shader clock rank 0's chip actually held over the timed region
+            out["step_roofline"]["clock_ghz_live"] = clock_live[0]
+            out["step_roofline"]["frac_of_live_clock_peak"] = out["step_roofline"]["achieved"] / (PEAK_FP16_TFLOPS * clock_live[0] / 2.4)
 
     # ---- per-kernel roofline of the dominant kernel, measured live with events on the launch stream
     if rehearse:
@@ -1271,6 +1293,13 @@ def main():
                            "clock_source": clock.get("source") if clock else None,
                            "clock_adjusted_peak": PEAK_FP16_TFLOPS * clk_ghz / 2.4 if clk_ghz else None,
                            "frac_of_clock_adjusted_peak": (gf / gt / 1e12) / (PEAK_FP16_TFLOPS * clk_ghz / 2.4) if clk_ghz else None,
+                           # measured in THIS run: the shader clock the chip held over the timed region (every kernel of the
+                           # step, not only these), from stamps of s_memtime against the 100 MHz counter (sp_clock_stamp)
+                           "clock_ghz_live": clock_live[0] if clock_live else None,
+                           "clock_live_window_s": clock_live[1] if clock_live else None,
+                           "clock_live_xcds": clock_live[2] if clock_live else None,
+                           "frac_of_live_clock_peak": ((gf / gt / 1e12) / (PEAK_FP16_TFLOPS * clock_live[0] / 2.4)
+                                                       if clock_live and clock_live[0] else None),
                            "traffic_source": traffic_src, "traffic_measured_at_commit": traffic_commit,
                            "pmc_dominant_template": pmc_dominant_template(),
                            "algorithmic_bytes_per_launch": gb / gn,

@@ -353,6 +353,15 @@ int sp_attn_small_f16(const void *q, const void *k, const void *v, void *o, int6
 int sp_gelu_f16(const void *x, void *y, int64_t n, int quick, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Measurement aid (bench.py `roofline.clock_ghz_live`; the reference has no counterpart -- its benchmark reads no clocks,
+ * /root/reference/src/modes/benchmark.py:170-262).  One time stamp in stream order: `blocks` one-wave workgroups each write
+ * four u64 words to out[block][4]: the id of the XCD the workgroup ran on (HW_REG_XCC_ID), the shader-clock counter
+ * (s_memtime), the constant 100 MHz counter (s_memrealtime), and 1.  Two stamps taken on the same XCD before and after a
+ * stretch of work give the shader clock held in between: GHz = 0.1 * (shader ticks) / (100-MHz ticks).
+ * ------------------------------------------------------------------------------------------- */
+int sp_clock_stamp(void *out, int blocks, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * DummyUNet (simulator-path model, /root/reference/src/models/dummy_unet.py:37-59), fp32 NCDHW:
  * out = x + gain*Conv3d(SiLU(Conv3d(x))) + LayerNorm_C(x).  hidden: scratch [B][hidden][F][H][W].
  * ------------------------------------------------------------------------------------------- */

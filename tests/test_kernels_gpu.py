@@ -1201,3 +1201,31 @@ def test_dummy_unet_hip_matches_reference_golden(golden_dir):
             for s in z["timesteps"].tolist():
                 lat = model(lat, s)
         check(lat, torch.from_numpy(z["final"]), l2=1e-5, mx=1e-4)
+
+
+def test_clock_stamps_bracket_work():
+    """sp_clock_stamp (bench.py `roofline.clock_ghz_live`): two stamps around ~tens of ms of contractions give a shader clock
+    between idle and the 2.4 GHz the peak assumes, over a window that matches the host's clock, on at least one XCD."""
+    import time
+    ops = _ops()
+    a = torch.randn(8192, 1280, device=DEV, dtype=torch.float16)
+    w = torch.randn(5120, 1280, device=DEV, dtype=torch.float16) * 0.02
+    out = torch.empty(8192, 5120, device=DEV, dtype=torch.float16)
+    for _ in range(3):
+        ops.gemm(a, w, out, m=8192, n=5120, cin=1280)
+    st = ops.ClockStamps(torch.device(DEV), 4)
+    assert st.ghz() is None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st.stamp()
+    for _ in range(200):
+        ops.gemm(a, w, out, m=8192, n=5120, cin=1280)
+    st.stamp()
+    torch.cuda.synchronize()
+    host = time.perf_counter() - t0
+    ghz, secs, xcds = st.ghz()
+    assert 0.3 < ghz <= 2.6, ghz
+    assert 1 <= xcds <= 8
+    assert 0.5 * host < secs < 1.05 * host + 1e-3, (secs, host)
+    assert ops.load().sp_clock_stamp(0, 64, 0) != 0          # a null pointer is refused, nothing is launched
+    assert ops.load().sp_clock_stamp(st.buf.data_ptr(), 0, 0) != 0

@@ -245,3 +245,29 @@ extern "C" int sp_sinusoid_f16(const float *values, void *out, int count, int di
   SP_CHECK_LAUNCH("sp_sinusoid_f16");
   return SP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Measurement aid (bench.py `roofline.clock_ghz_live`): a time stamp of both counters a wave can read -- the shader-clock
+// counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) -- from `blocks` one-wave workgroups, each with the
+// id of the XCD it ran on (the shader-clock counters of different XCDs are not assumed to share an origin).  Two stamps on
+// the same XCD, one before and one after a stretch of work, give the shader clock the chip held in between:
+// 0.1 GHz x (shader ticks) / (100 MHz ticks).  No persistent kernel: a stamp is a ~2 us launch in stream order.
+namespace {
+__global__ void clock_stamp_kernel(unsigned long long *out) {
+  if (threadIdx.x != 0) return;
+  unsigned long long *o = out + (size_t)blockIdx.x * 4;
+  o[0] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);     // HW_REG_XCC_ID, bits 3:0
+  o[1] = __builtin_amdgcn_s_memtime();
+  o[2] = wall_clock64();
+  o[3] = 1;
+}
+}  // namespace
+
+extern "C" int sp_clock_stamp(void *out, int blocks, void *stream) {
+  SP_REQUIRE(out && ((uintptr_t)out & 7) == 0, "sp_clock_stamp: out must be an 8-byte aligned device pointer");
+  SP_REQUIRE(blocks > 0 && blocks <= 1024, "sp_clock_stamp: blocks=%d outside (0, 1024]", blocks);
+  SP_CLEAR_STALE_ERROR();
+  hipLaunchKernelGGL(clock_stamp_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, (unsigned long long *)out);
+  SP_CHECK_LAUNCH("sp_clock_stamp");
+  return SP_OK;
+}

@@ -85,6 +85,7 @@ SIGNATURES = {
     "sp_patchify_f16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "sp_attn_small_f16": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _F, _P]),
     "sp_gelu_f16": (_I, [_P, _P, _L, _I, _P]),
+    "sp_clock_stamp": (_I, [_P, _I, _P]),
     "sp_dummy_unet_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _F, _I, _I, _I, _I, _I, _I, _P]),
 }
 

@@ -401,6 +401,42 @@ def gelu(x, y, *, quick=False):
     return y
 
 
+class ClockStamps:
+    """Stamps of the shader-clock counter against the constant 100 MHz counter, taken in stream order between other work
+    (``sp_clock_stamp``; bench.py ``roofline.clock_ghz_live``).  ``stamp()`` enqueues one on the current stream (a ~2 us
+    launch of 64 one-wave workgroups, each noting the XCD it ran on); ``ghz()`` (after a synchronise) pairs the first and the
+    last stamp XCD by XCD and returns (GHz, seconds between the stamps, XCDs seen in both) -- the shader clock the chip held
+    over that stretch -- or None with fewer than two stamps."""
+    BLOCKS = 64
+
+    def __init__(self, device, capacity):
+        import torch
+        self.buf = torch.zeros((capacity, self.BLOCKS, 4), dtype=torch.int64, device=device)
+        self.n = 0
+
+    def stamp(self):
+        if self.n < self.buf.shape[0]:
+            _check(load().sp_clock_stamp(self.buf[self.n].data_ptr(), self.BLOCKS, _stream()), "sp_clock_stamp")
+            self.n += 1
+
+    def ghz(self):
+        if self.n < 2:
+            return None
+        b = self.buf[:self.n].cpu()
+        real = b[:, :, 2].double().mean(dim=1)                 # when each stamp ran (its workgroups: within microseconds)
+        first, last = b[int(real.argmin())], b[int(real.argmax())]
+        ratios, secs = [], []
+        for x in sorted(set(first[:, 0].tolist()) & set(last[:, 0].tolist())):
+            f, l = first[first[:, 0] == x][0], last[last[:, 0] == x][0]
+            dr = int(l[2] - f[2])
+            if dr > 0:
+                ratios.append(0.1 * int(l[1] - f[1]) / dr)
+                secs.append(dr / 1e8)
+        if not ratios:
+            return None
+        return sum(ratios) / len(ratios), sum(secs) / len(secs), len(ratios)
+
+
 def euler_step(latent, eps_cond, eps_uncond, guidance, out, *, ld_eps, sigma, sigma_next, b, frames, h, w):
     _check(load().sp_euler_step_f16(latent.data_ptr(), eps_cond.data_ptr(), _ptr(eps_uncond), ld_eps, _ptr(guidance),
                                     out.data_ptr(), sigma, sigma_next, b, frames, h, w, _stream()), "sp_euler_step_f16")
