@@ -15,7 +15,8 @@ send/recv on a side stream (``vdpp_amd.pipeline.PipelineStage``).
 The JSON line carries: metric/value (K videos / max-over-ranks wall time of the barrier-bracketed timed
 region), ``roofline`` for the dominant kernel (the implicit-GEMM MFMA kernel: algorithmic FLOPs of its
 launches in one UNet forward / their summed HIP-event durations, vs the 2.5 PFLOP/s dense fp16 peak),
-``step_roofline`` (whole UNet forward), ``cpu_baseline`` (the oracle's fp32 UNet restatement timed on the
+``step_roofline`` (whole UNet forward; both with ``clock_ghz_live`` = the shader clock rank 0's chip held over the timed
+region, from stream-ordered stamps of s_memtime against the 100 MHz counter), ``cpu_baseline`` (the oracle's fp32 UNet restatement timed on the
 host cores on a bounded sample, rank 0 at N=1 only) and ``cpu_simulator`` (the reference's CPU
 simulator-mode path = DummyUNet step pipeline, as re-implemented here + the C oracle).
 """
