@@ -1092,7 +1092,7 @@ def main():
         stamps = None
         if cuda and not rehearse and rank == 0:
             try:
-                stamps = ops.ClockStamps(device, n_samples + 2)
+                stamps = ops.ClockStamps(device, n_samples + 3)
             except Exception as exc:  # noqa: BLE001
                 print(f"bench.py: no clock stamps ({exc!r})", file=sys.stderr, flush=True)
 
@@ -1114,6 +1114,9 @@ def main():
         clock_live = None
         if stamps is not None:
             try:
+                if stamps.n < 2:                 # chain: rank 0 finishes no sample itself -- a closing stamp behind the fence
+                    stamps.stamp()
+                    torch.cuda.synchronize(device)
                 clock_live = stamps.ghz()        # (GHz, seconds between the first and the last stamp, XCDs paired)
             except Exception as exc:  # noqa: BLE001
                 print(f"bench.py: clock stamps unreadable ({exc!r})", file=sys.stderr, flush=True)
