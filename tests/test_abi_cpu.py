@@ -77,3 +77,31 @@ def test_documented_binding_in_integration_md_matches_the_library():
     doc_struct = type("DocGemmDesc", (ctypes.Structure,), {"_fields_": mirror})
     assert ctypes.sizeof(doc_struct) == hip.load().sp_gemm_desc_size()
     assert "sp_gemm_desc_size()" in block and "raise" in block, "the documented stub must refuse a size mismatch"
+
+
+def test_clock_stamps_pair_first_and_last_stamp_per_xcd():
+    """ops.ClockStamps.ghz() (host logic of bench.py's `roofline.clock_ghz_live`): the first and the last stamp are paired XCD by
+    XCD -- the shader-clock counters of different XCDs need not share an origin -- and the clock is 0.1 GHz x shader ticks per
+    100 MHz tick; fewer than two stamps give None.  No GPU: the stamp records are written by hand."""
+    import torch
+    from vdpp_amd.hip import ops
+    st = ops.ClockStamps(torch.device("cpu"), 3)
+    assert st.ghz() is None
+    origin = {0: 10**9, 1: 5 * 10**12, 5: 77}               # per-XCD origins of the shader-clock counter
+    def write(slot, real, ghz):
+        for b in range(st.BLOCKS):
+            x = (0, 1, 5)[b % 3]
+            st.buf[slot, b, 0] = x
+            st.buf[slot, b, 1] = origin[x] + int(real * ghz * 10)     # shader ticks at `ghz` since real tick 0
+            st.buf[slot, b, 2] = 4000 + real + (b % 2)                # workgroups of one stamp run within a tick or two
+            st.buf[slot, b, 3] = 1
+    write(1, 0, 1.8)                 # slots in any order: ghz() orders stamps by their 100 MHz time
+    write(0, 2_000_000, 1.8)         # 20 ms later
+    write(2, 1_000_000, 1.8)
+    st.n = 3
+    ghz, secs, xcds = st.ghz()
+    assert xcds == 3
+    assert abs(ghz - 1.8) < 1e-3
+    assert abs(secs - 0.02) < 1e-4
+    st.n = 1
+    assert st.ghz() is None
